@@ -1,0 +1,286 @@
+// Tiled Gaussian blue-noise generator for gfx950: out = unvec(L . vec(z)) per 64x64 tile, fused
+// with the reference's tile gather / batch-major re-read / noise_padding / white<->blue lerp.
+//
+// Stands in for get_noise_v2 (bluenoise/get_noise_recent.py:23-196): torch.matmul(cov_mat_L, noise)
+// (:88,:113,:146) + view/permute/contiguous (:111,:143-146) + torch.cat tile split and noise_padding
+// (:131-133, :7-19) + lerp (:91,:116,:160).
+//
+// Two launches:
+//   1. bluenoise_gemm<NT>: exact-f32 MFMA (v_mfma_f32_32x32x2_f32 == an fmaf chain) over the LOWER
+//      TRIANGLE of L only.  A block owns 64 rows of L x (64*NT) z-columns x one 1024-wide k segment;
+//      L and z tiles are staged with 16-byte global_load_lds into XOR-swizzled LDS images
+//      (double-buffered), so every byte of L is fetched from HBM in full 256-B row pieces and
+//      ds_read_b128 fragment reads are bank-conflict free.  Partial sums go to per-segment slabs
+//      (deterministic: no atomics).
+//   2. bluenoise_finish: sums the <=4 slabs in fixed order and writes noise / noise_bn / noise_wn
+//      in the reference's output layouts (32-px crop, 128-px slot placement and the scrambled
+//      white-noise view), with the per-sample lerp evaluated in the reference's operation order.
+//
+// Algorithmic work: 4*T(4096) = 33,562,624 B of L read once, 2*T(4096)*n flop.
+#include "common.hpp"
+
+namespace bndm {
+
+namespace {
+
+constexpr int NPIX = 4096;
+constexpr int BM = 64;       // rows of L per block
+constexpr int BK = 64;       // k per LDS stage
+constexpr int KSEG = 1024;   // k per work unit
+constexpr int NSEG = NPIX / KSEG;
+
+struct ZSrc {
+    const float *z;
+    int layout;
+    int B_global;
+    int C;
+};
+
+// &z(fcol, c, j).  For j % 4 == 0 the 4 floats j..j+3 are contiguous in every layout.
+__device__ __forceinline__ const float *z_addr(const ZSrc &s, int fcol, int c, int j) {
+    const int jy = j >> 6, jx = j & 63;
+    if (s.layout == BNDM_Z_COLUMNS) return s.z + ((size_t)(fcol * s.C + c)) * NPIX + j;
+    if (s.layout == BNDM_Z_IMAGE32)
+        return s.z + ((size_t)(fcol * s.C + c)) * 1024 + (jy & 31) * 32 + (jx & 31);
+    const int k = fcol / s.B_global, b = fcol - k * s.B_global;      // tile-major: f = k*B + b
+    const int r0 = (k >> 1) * 64, c0 = (k & 1) * 64;                 // TL, TR, BL, BR
+    return s.z + (((size_t)(b * s.C + c)) * 128 + r0 + jy) * 128 + c0 + jx;
+}
+
+// offset (in floats) of tile row jy relative to tile row 0, per layout
+__device__ __forceinline__ int z_row_off(int layout, int jy) {
+    if (layout == BNDM_Z_COLUMNS) return jy * 64;
+    if (layout == BNDM_Z_IMAGE32) return (jy & 31) * 32;
+    return jy * 128;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void bluenoise_gemm(const float *__restrict__ L, ZSrc zs,
+                                                      float *__restrict__ part, int ncols,
+                                                      int f_begin, int dense) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BN = 64 * NT;
+    constexpr int L_BYTES = BM * BK * 4;
+    constexpr int Z_BYTES = BN * BK * 4;
+    constexpr int STAGE = L_BYTES + Z_BYTES;
+
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63;
+
+    // ---- work unit: (row panel p, k segment), heaviest panels first --------------------------
+    const int u = blockIdx.x;
+    int p, seg;
+    if (dense || u < 64) { p = 63 - (u >> 2); seg = u & 3; }
+    else if (u < 112)    { const int v = u - 64;  p = 47 - v / 3;    seg = v % 3; }
+    else if (u < 144)    { const int v = u - 112; p = 31 - (v >> 1); seg = v & 1; }
+    else                 { p = 15 - (u - 144); seg = 0; }
+    const int i0 = p * BM;
+    const int kbeg = seg * KSEG;
+    const int kend = dense ? kbeg + KSEG : min(kbeg + KSEG, i0 + BM);
+    const int nchunks = (kend - kbeg) / BK;
+    const int col0 = blockIdx.y * BN;
+
+    // ---- per-thread staging descriptors ------------------------------------------------------
+    const int q = w * 64 + l;                 // 16-byte piece index inside one 4-KB block-instruction
+    const int prow = q >> 4;                  // 0..15
+    const int pchunk = q & 15;                // physical 16-B chunk inside the 256-B LDS row
+    const int lchunk = pchunk ^ (prow & 15);  // logical chunk stored there (rows r*16+prow: same key)
+    const float *lsrc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        lsrc[r] = L + (size_t)(i0 + r * 16 + prow) * NPIX + kbeg + 4 * lchunk;
+    const float *zsrc[4 * NT];
+#pragma unroll
+    for (int r = 0; r < 4 * NT; ++r) {
+        int lc = col0 + r * 16 + prow;
+        lc = lc < ncols ? lc : ncols - 1;
+        const int fl = lc / zs.C;
+        zsrc[r] = z_addr(zs, f_begin + fl, lc - fl * zs.C, 4 * lchunk);
+    }
+    const int jy0 = kbeg >> 6;
+
+    auto stage = [&](int buf, int t) {
+        char *base = smem + buf * STAGE;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            glds16(lsrc[r] + t * BK, base + r * 4096 + w * 1024);
+        const int zoff = z_row_off(zs.layout, jy0 + t);
+#pragma unroll
+        for (int r = 0; r < 4 * NT; ++r)
+            glds16(zsrc[r] + zoff, base + L_BYTES + r * 4096 + w * 1024);
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    const int wi = w & 1, wj = w >> 1;
+    const int frow = l & 31, kh = l >> 5;
+    const int key = l & 15;
+    const int lrow = wi * 32 + frow;
+
+    if (nchunks > 0) {
+        stage(0, 0);
+        wait_vmem_all();
+        __syncthreads();
+    }
+    int cur = 0;
+    for (int t = 0; t < nchunks; ++t) {
+        if (t + 1 < nchunks) stage(cur ^ 1, t + 1);
+        const float *Lt = reinterpret_cast<const float *>(smem + cur * STAGE);
+        const float *Zt = reinterpret_cast<const float *>(smem + cur * STAGE + L_BYTES);
+#pragma unroll
+        for (int s = 0; s < BK / 8; ++s) {
+            const int pc = ((2 * s + kh) ^ key) * 4;
+            const f32x4 lf = *reinterpret_cast<const f32x4 *>(Lt + lrow * BK + pc);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                const int zrow = wj * 32 * NT + tt * 32 + frow;
+                const f32x4 zf = *reinterpret_cast<const f32x4 *>(Zt + zrow * BK + pc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(zf[e], lf[e], acc[tt], 0, 0, 0);
+            }
+        }
+        wait_vmem_all();
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- D rows = z columns, D cols = L rows: 128-B contiguous stores along i ----------------
+    float *pseg = part + (size_t)seg * ncols * NPIX;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int lc = col0 + wj * 32 * NT + tt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+            if (lc < ncols) pseg[(size_t)lc * NPIX + i0 + lrow] = acc[tt][e];
+        }
+}
+
+__global__ __launch_bounds__(256) void bluenoise_finish(const float *__restrict__ part, ZSrc zs,
+                                                        const float *__restrict__ alpha,
+                                                        float *__restrict__ noise,
+                                                        float *__restrict__ noise_bn,
+                                                        float *__restrict__ noise_wn, int ncols,
+                                                        int b_begin, int b_count, int res, int mode,
+                                                        int dense) {
+    const int C = zs.C;
+    const size_t total = (size_t)b_count * C * res * res;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int X = (int)(idx % res);
+        const int Y = (int)((idx / res) % res);
+        const int c = (int)((idx / ((size_t)res * res)) % C);
+        const int bl = (int)(idx / ((size_t)res * res * C));
+        const int b = b_begin + bl;
+        int i, fcol, lc;
+        if (res == 128) {
+            const int slot = (Y >> 6) + 2 * (X >> 6);          // noise_padding placement (:10-14)
+            i = (Y & 63) * 64 + (X & 63);
+            fcol = 4 * b + slot;                               // batch-major re-read (:144,:146)
+            lc = (fcol - 4 * b_begin) * C + c;
+        } else {
+            i = Y * 64 + X;                                    // 32 px: crop of the 64 grid (:97-99)
+            fcol = b;
+            lc = bl * C + c;
+        }
+        float wn;
+        if (res == 128) {                                      // [4096, C] buffer re-read as [C, 4096]
+            const int qq = c * NPIX + i;
+            const int j = qq / C;
+            wn = *z_addr(zs, fcol, qq - j * C, j);
+        } else {
+            wn = *z_addr(zs, fcol, c, i);
+        }
+        float out;
+        if (mode == BNDM_NOISE_SCRAMBLE) {
+            out = wn;
+        } else {
+            const int nseg = dense ? NSEG : ((i >> 6) >> 4) + 1;
+            float bn = part[(size_t)lc * NPIX + i];
+            for (int s = 1; s < nseg; ++s) bn = __fadd_rn(bn, part[((size_t)s * ncols + lc) * NPIX + i]);
+            if (noise_bn) noise_bn[idx] = bn;
+            if (mode == BNDM_NOISE_BLEND) {
+                const float a = alpha[b];
+                out = __fadd_rn(__fmul_rn(bn, __fsub_rn(1.0f, a)), __fmul_rn(wn, a));
+            } else {
+                out = bn;
+            }
+        }
+        if (noise_wn) noise_wn[idx] = wn;
+        if (noise) noise[idx] = out;
+    }
+}
+
+template <int NT>
+int launch_gemm(const float *L, const ZSrc &zs, float *part, int ncols, int f_begin, int dense,
+                hipStream_t st) {
+    constexpr int BN = 64 * NT;
+    constexpr int smem = 2 * (BM * BK * 4 + BN * BK * 4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        BNDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bluenoise_gemm<NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    dim3 grid(dense ? 256 : 160, ceil_div(ncols, BN));
+    hipLaunchKernelGGL(bluenoise_gemm<NT>, grid, dim3(256), smem, st, L, zs, part, ncols, f_begin, dense);
+    return launch_status("bluenoise_gemm");
+}
+
+}  // namespace
+}  // namespace bndm
+
+using namespace bndm;
+
+extern "C" size_t bndm_bluenoise_workspace_bytes(int b_count, int C, int res) {
+    if (b_count <= 0 || C <= 0) return 0;
+    const size_t ncols = (size_t)b_count * C * (res == 128 ? 4 : 1);
+    return (size_t)NSEG * ncols * NPIX * sizeof(float);
+}
+
+extern "C" int bndm_bluenoise(const float *L, int l_dense, const float *z, int z_layout,
+                              const float *alpha, float *noise, float *noise_bn, float *noise_wn,
+                              int B_global, int b_begin, int b_count, int C, int res, int mode,
+                              void *workspace, size_t workspace_bytes, void *stream) {
+    BNDM_REQUIRE(res == 32 || res == 64 || res == 128,
+                 "bndm_bluenoise: unsupported width %d (reference raises NotImplementedError, "
+                 "get_noise_recent.py:166-167)", res);
+    BNDM_REQUIRE(z != nullptr, "bndm_bluenoise: z is NULL");
+    BNDM_REQUIRE(B_global > 0 && C > 0 && b_begin >= 0 && b_count >= 0 && b_begin + b_count <= B_global,
+                 "bndm_bluenoise: bad batch range [%d,+%d) of %d", b_begin, b_count, B_global);
+    BNDM_REQUIRE(mode == BNDM_NOISE_BLEND || mode == BNDM_NOISE_PURE_BN || mode == BNDM_NOISE_SCRAMBLE,
+                 "bndm_bluenoise: bad mode %d", mode);
+    BNDM_REQUIRE(z_layout == BNDM_Z_COLUMNS || (z_layout == BNDM_Z_IMAGE32 && res == 32) ||
+                     (z_layout == BNDM_Z_IMAGE128 && res == 128),
+                 "bndm_bluenoise: z_layout %d does not fit width %d", z_layout, res);
+    BNDM_REQUIRE(mode != BNDM_NOISE_SCRAMBLE || res == 128, "bndm_bluenoise: scramble is 128-px only");
+    BNDM_REQUIRE(mode != BNDM_NOISE_BLEND || alpha != nullptr, "bndm_bluenoise: alpha is NULL");
+    if (b_count == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int ncols = b_count * C * (res == 128 ? 4 : 1);
+    const int f_begin = res == 128 ? 4 * b_begin : b_begin;
+    ZSrc zs{z, z_layout, B_global, C};
+    float *part = (float *)workspace;
+    if (mode != BNDM_NOISE_SCRAMBLE) {
+        BNDM_REQUIRE(L != nullptr, "bndm_bluenoise: L is NULL");
+        BNDM_REQUIRE(workspace != nullptr &&
+                         workspace_bytes >= bndm_bluenoise_workspace_bytes(b_count, C, res),
+                     "bndm_bluenoise: workspace too small (%zu < %zu)", workspace_bytes,
+                     bndm_bluenoise_workspace_bytes(b_count, C, res));
+        int rc;
+        if (ncols <= 64) rc = launch_gemm<1>(L, zs, part, ncols, f_begin, l_dense ? 1 : 0, st);
+        else if (ncols <= 128) rc = launch_gemm<2>(L, zs, part, ncols, f_begin, l_dense ? 1 : 0, st);
+        else rc = launch_gemm<3>(L, zs, part, ncols, f_begin, l_dense ? 1 : 0, st);
+        if (rc) return rc;
+    }
+    const size_t total = (size_t)b_count * C * res * res;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(bluenoise_finish, dim3(blocks), dim3(256), 0, st, part, zs, alpha, noise, noise_bn,
+                       noise_wn, ncols, b_begin, b_count, res, mode, l_dense ? 1 : 0);
+    return launch_status("bluenoise_finish");
+}

@@ -1,0 +1,55 @@
+// Shared helpers for libbndm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+#include "../../include/bndm_hip.h"
+
+namespace bndm {
+
+void set_error(const char *fmt, ...);
+
+#define BNDM_CHECK_HIP(expr)                                                              \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            ::bndm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                              __FILE__, __LINE__);                                        \
+            return (int)_e;                                                               \
+        }                                                                                 \
+    } while (0)
+
+#define BNDM_REQUIRE(cond, ...)                                                           \
+    do {                                                                                  \
+        if (!(cond)) {                                                                    \
+            ::bndm::set_error(__VA_ARGS__);                                               \
+            return BNDM_E_ARG;                                                            \
+        }                                                                                 \
+    } while (0)
+
+static inline int launch_status(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// 16-byte asynchronous global -> LDS copy (global_load_lds_dwordx4).  `lds_wave_base` must be
+// wave-uniform; lane l's 16 bytes land at lds_wave_base + 16*l.  The global source is per lane.
+__device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void *)gsrc,
+        (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void wait_vmem_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace bndm
