@@ -161,6 +161,7 @@ __global__ __launch_bounds__(256) void bluenoise_gemm(const float *__restrict__ 
         }
 }
 
+#pragma clang fp contract(off)   // lerp evaluated as torch does: two rounded products, one add
 __global__ __launch_bounds__(256) void bluenoise_finish(const float *__restrict__ part, ZSrc zs,
                                                         const float *__restrict__ alpha,
                                                         float *__restrict__ noise,
@@ -202,11 +203,11 @@ __global__ __launch_bounds__(256) void bluenoise_finish(const float *__restrict_
         } else {
             const int nseg = dense ? NSEG : ((i >> 6) >> 4) + 1;
             float bn = part[(size_t)lc * NPIX + i];
-            for (int s = 1; s < nseg; ++s) bn = __fadd_rn(bn, part[((size_t)s * ncols + lc) * NPIX + i]);
+            for (int s = 1; s < nseg; ++s) bn = bn + part[((size_t)s * ncols + lc) * NPIX + i];
             if (noise_bn) noise_bn[idx] = bn;
             if (mode == BNDM_NOISE_BLEND) {
                 const float a = alpha[b];
-                out = __fadd_rn(__fmul_rn(bn, __fsub_rn(1.0f, a)), __fmul_rn(wn, a));
+                out = bn * (1.0f - a) + wn * a;
             } else {
                 out = bn;
             }

@@ -4,6 +4,10 @@
 //   export_u8  : iadb_bn.py:815-816 (truncate) / ddim_diffusers.py:687-688 (round half even)
 #include "common.hpp"
 
+// bit-exact parity with torch's separate mul/add kernels: products and sums are written as plain
+// operators and fma contraction is forbidden in this file (header intrinsics would still fuse)
+#pragma clang fp contract(off)
+
 namespace bndm {
 namespace {
 
@@ -21,11 +25,11 @@ __global__ __launch_bounds__(256) void iadb_step_kernel(float *__restrict__ x, c
         f32x4 xv = reinterpret_cast<f32x4 *>(x)[i];
         const f32x4 d1 = reinterpret_cast<const f32x4 *>(d)[(b * Cout + c) * HW4 + p];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) xv[e] = __fadd_rn(xv[e], __fmul_rn(da, d1[e]));
+        for (int e = 0; e < 4; ++e) xv[e] = xv[e] + da * d1[e];
         if (Cout == 2 * C) {
             const f32x4 d2 = reinterpret_cast<const f32x4 *>(d)[(b * Cout + C + c) * HW4 + p];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) xv[e] = __fadd_rn(xv[e], __fmul_rn(dg, d2[e]));
+            for (int e = 0; e < 4; ++e) xv[e] = xv[e] + dg * d2[e];
         }
         reinterpret_cast<f32x4 *>(x)[i] = xv;
     }
@@ -37,9 +41,9 @@ __global__ __launch_bounds__(256) void ddim_step_kernel(float *__restrict__ x, c
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x) {
         const float e = eps[i];
-        float x0 = __fdiv_rn(__fsub_rn(x[i], __fmul_rn(sqrt_1m_at, e)), sqrt_at);
+        float x0 = (x[i] - sqrt_1m_at * e) / sqrt_at;
         if (clip > 0.f) x0 = fminf(fmaxf(x0, -clip), clip);
-        x[i] = __fadd_rn(__fmul_rn(sqrt_ap, x0), __fmul_rn(sqrt_1m_ap, e));
+        x[i] = sqrt_ap * x0 + sqrt_1m_ap * e;
     }
 }
 
@@ -55,14 +59,14 @@ __global__ __launch_bounds__(256) void export_u8_kernel(const float *__restrict_
         const float v = x[(b * C + c) * HW + p];
         float y;
         if (rounding == 0) {
-            y = __fdiv_rn(__fadd_rn(v, 1.0f), 2.0f);          // (x + 1) / 2.0
+            y = (v + 1.0f) / 2.0f;                               // (x + 1) / 2.0
             y = fminf(fmaxf(y, 0.f), 1.f);
-            y = __fmul_rn(y, 255.0f);                         // numpy f32 * 255 -> astype(uint8)
+            y = y * 255.0f;                                      // numpy f32 * 255 -> astype(uint8)
             out[i] = (uint8_t)(int)y;
         } else {
-            y = __fadd_rn(__fdiv_rn(v, 2.0f), 0.5f);          // x / 2 + 0.5
+            y = v / 2.0f + 0.5f;                                 // x / 2 + 0.5
             y = fminf(fmaxf(y, 0.f), 1.f);
-            y = rintf(__fmul_rn(y, 255.0f));                  // .round() is half-to-even
+            y = rintf(y * 255.0f);                               // .round() is half-to-even
             out[i] = (uint8_t)(int)y;
         }
     }

@@ -1,1 +1,717 @@
-// kernels land next commit
+// UNet2DModel forward kernels for gfx950 (diffusers UNet2DModel as built at iadb_bn.py:205-282).
+//
+//   conv_igemm      implicit-GEMM convolution on v_mfma_f32_32x32x16_{f16,bf16}: NHWC 16-bit in,
+//                   fp32 accumulate.  K runs over up to 4 "segments" (source tensor x taps), which
+//                   expresses cat([h, skip]) inputs, the fused 1x1 conv_shortcut of ResnetBlock2D,
+//                   stride-2 Downsample2D and nearest-2x Upsample2D without materialising anything.
+//                   Both operands are staged by 16-byte global_load_lds into XOR-swizzled,
+//                   double-buffered LDS tiles ([rows][64 k] of 128 B; chunk ^= (row>>1)&7 makes the
+//                   ds_read_b128 fragment reads conflict-free); padding taps read a zero page.
+//                   D = W . X^T, so a lane owns 4 consecutive output channels of one pixel and the
+//                   epilogue (bias + time-embedding + residual) stores 8 B per lane into NHWC.
+//   conv_in         3x3 conv from the fp32 NCHW sample (K = 9*Cin <= 64) straight onto MFMA.
+//   gn_*            GroupNorm(32): slab partial sums -> per-(sample, channel) scale/shift -> apply(+SiLU)
+//   attention       softmax(q k^T / sqrt(8)) v for 8-wide heads over <= a few hundred tokens
+//   temb_mlp        sinusoidal Timesteps -> Linear -> SiLU -> Linear -> SiLU (fp32)
+#include "unet_kernels.hpp"
+#include <cmath>
+
+namespace bndm {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct TT;
+template <> struct TT<_Float16> {
+    using v8 = f16x8;
+    using v4 = f16x4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct TT<__bf16> {
+    using v8 = bf16x8;
+    using v4 = bf16x4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+
+// ------------------------------------------------------------------------------------------------
+// implicit-GEMM convolution
+// ------------------------------------------------------------------------------------------------
+struct KIter {
+    int seg, tap, chunk, nchunk, taps;
+};
+
+__device__ __forceinline__ void kiter_load(KIter &k, const ConvArgs &a) {
+    k.nchunk = a.seg[k.seg].C >> 6;
+    k.taps = a.seg[k.seg].taps;
+}
+__device__ __forceinline__ void kiter_init(KIter &k, const ConvArgs &a, int ks) {
+    k.seg = 0;
+    for (;;) {
+        const int n = a.seg[k.seg].taps * (a.seg[k.seg].C >> 6);
+        if (ks < n || k.seg == a.nseg - 1) break;
+        ks -= n;
+        ++k.seg;
+    }
+    kiter_load(k, a);
+    k.tap = ks / k.nchunk;
+    k.chunk = ks - k.tap * k.nchunk;
+}
+__device__ __forceinline__ void kiter_next(KIter &k, const ConvArgs &a) {
+    if (++k.chunk == k.nchunk) {
+        k.chunk = 0;
+        if (++k.tap == k.taps) {
+            k.tap = 0;
+            if (k.seg < a.nseg - 1) ++k.seg;
+            kiter_load(k, a);
+        }
+    }
+}
+
+template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int EPI>
+__global__ __launch_bounds__(256) void conv_igemm(const ConvArgs a, const int ksteps, const int logW,
+                                                  const int logH, const int ntm, const int ntn) {
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+    constexpr int BM = WAVES_M * TM * 32;   // output pixels per block
+    constexpr int BN = WAVES_N * TN * 32;   // output channels per block
+    constexpr int X_BYTES = BM * 128;
+    constexpr int W_BYTES = BN * 128;
+    constexpr int STAGE = X_BYTES + W_BYTES;
+    constexpr int NXP = BM / 32;            // 16-B pieces per thread per stage (activations)
+    constexpr int NWP = BN / 32;            // (weights)
+    using v8 = typename TT<T>::v8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63;
+
+    // ---- XCD-aware tile id: consecutive tiles (shared halos / shared weights) stay on one XCD -----
+    const int nblk = ntm * ntn;
+    int tix;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        tix = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mt = tix / ntn, nt = tix - mt * ntn;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int M = a.B << (logW + logH);
+    const int H = a.H, Wd = a.W;
+
+    // ---- split-K range ------------------------------------------------------------------------------
+    int ks_begin = 0, ks_end = ksteps;
+    if (a.splitk > 1) {
+        const int per = (ksteps + a.splitk - 1) / a.splitk;
+        ks_begin = blockIdx.y * per;
+        ks_end = min(ksteps, ks_begin + per);
+    }
+    const int nsteps = max(0, ks_end - ks_begin);
+
+    // ---- per-thread staging descriptors -----------------------------------------------------------
+    const int prow = tid >> 3;                       // 0..31
+    const int lchunk = (tid & 7) ^ ((tid >> 4) & 7); // logical 16-B chunk this lane fetches
+    int px[NXP], py[NXP], pb[NXP];
+#pragma unroll
+    for (int i = 0; i < NXP; ++i) {
+        const int m = m0 + prow + 32 * i;
+        px[i] = m & (Wd - 1);
+        py[i] = (m >> logW) & (H - 1);
+        pb[i] = (m < M) ? (m >> (logW + logH)) : -1;
+    }
+    const char *wsrc[NWP];
+#pragma unroll
+    for (int i = 0; i < NWP; ++i)
+        wsrc[i] = (const char *)a.Wgt + ((size_t)(n0 + prow + 32 * i) * a.Ktot + lchunk * 8) * 2;
+
+    auto stage = [&](int buf, const KIter &k, int ks) {
+        char *base = smem + buf * STAGE;
+        const ConvSeg sg = a.seg[k.seg];
+        int dy = 0, dx = 0;
+        if (sg.taps == 9) {
+            dy = k.tap / 3 - 1;
+            dx = k.tap - (dy + 1) * 3 - 1;
+        }
+        const int coff = k.chunk * 64 + lchunk * 8;
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {
+            int iy, ix, Hs, Ws;
+            bool ok;
+            if (sg.up) {
+                const int uy = py[i] + dy, ux = px[i] + dx;
+                ok = (unsigned)uy < (unsigned)H && (unsigned)ux < (unsigned)Wd;
+                iy = uy >> 1; ix = ux >> 1; Hs = H >> 1; Ws = Wd >> 1;
+            } else {
+                iy = py[i] * a.stride + dy; ix = px[i] * a.stride + dx;
+                Hs = H * a.stride; Ws = Wd * a.stride;
+                ok = (unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws;
+            }
+            ok = ok && pb[i] >= 0;
+            const size_t off = ((size_t)((pb[i] * Hs + iy) * Ws + ix) * sg.C + coff) * 2;
+            const char *src = ok ? (const char *)sg.src + off : (const char *)a.zeros;
+            glds16(src, base + i * 4096 + w * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < NWP; ++i)
+            glds16(wsrc[i] + (size_t)ks * 128, base + X_BYTES + i * 4096 + w * 1024);
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int wm = w % WAVES_M, wn = w / WAVES_M;
+    const int frow = l & 31, kh = l >> 5, key = (l >> 1) & 7;
+
+    KIter kit;
+    kiter_init(kit, a, ks_begin);
+    if (nsteps > 0) {
+        stage(0, kit, ks_begin);
+        kiter_next(kit, a);
+        wait_vmem_all();
+        __syncthreads();
+    }
+    int cur = 0;
+    for (int it = 0; it < nsteps; ++it) {
+        if (it + 1 < nsteps) {
+            stage(cur ^ 1, kit, ks_begin + it + 1);
+            kiter_next(kit, a);
+        }
+        const char *Xt = smem + cur * STAGE;
+        const char *Wt = Xt + X_BYTES;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int pc = ((2 * s + kh) ^ key) * 16;
+            v8 af[TN], bf[TM];
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                af[i] = *reinterpret_cast<const v8 *>(Wt + (wn * TN * 32 + i * 32 + frow) * 128 + pc);
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                bf[j] = *reinterpret_cast<const v8 *>(Xt + (wm * TM * 32 + j * 32 + frow) * 128 + pc);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = TT<T>::mfma(af[i], bf[j], acc[i][j]);
+        }
+        wait_vmem_all();
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: lane owns pixel (l&31) of each M-tile and channels 8g + 4*kh + {0..3} -----------
+    const int HW = 1 << (logW + logH);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + wm * TM * 32 + j * 32 + frow;
+        if (m >= M) continue;
+        const int b = m >> (logW + logH);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = n0 + wn * TN * 32 + i * 32 + 8 * g + 4 * kh;
+                if (co >= a.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                if (EPI == EPI_NCHW32) {
+                    float *o = (float *)a.out;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < a.Cout)
+                            o[((size_t)b * a.Cout + co + e) * HW + (m & (HW - 1))] =
+                                v[e] + (a.bias ? a.bias[co + e] : 0.f);
+                    continue;
+                }
+                if (a.splitk <= 1) {
+                    if (a.bias) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.bias + co);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                    }
+                    if (a.temb) {
+                        const f32x4 tv = *reinterpret_cast<const f32x4 *>(a.temb + (size_t)b * a.temb_bstride +
+                                                                           a.temb_off + co);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += tv[e];
+                    }
+                }
+                if (EPI == EPI_F32_ROWS) {
+                    float *o = (float *)a.out + (a.splitk > 1 ? (size_t)blockIdx.y * M * a.Cout : 0);
+                    f32x4 ov = {v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4 *>(o + (size_t)m * a.Cout + co) = ov;
+                } else {
+                    using v4 = typename TT<T>::v4;
+                    if (a.resid) {
+                        const v4 rv = *reinterpret_cast<const v4 *>((const T *)a.resid + (size_t)m * a.Cout + co);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                    }
+                    v4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = (T)v[e];
+                    *reinterpret_cast<v4 *>((T *)a.out + (size_t)m * a.Cout + co) = ov;
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ part, int splitk,
+                                                            const ConvArgs a, int logHW) {
+    using v4 = typename TT<T>::v4;
+    const size_t M = (size_t)a.B << logHW;
+    const int C4 = a.Cout >> 2;
+    const size_t total = M * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / C4;
+        const int co = (int)(i - m * C4) * 4;
+        f32x4 s = *reinterpret_cast<const f32x4 *>(part + m * a.Cout + co);
+        for (int z = 1; z < splitk; ++z) {
+            const f32x4 p = *reinterpret_cast<const f32x4 *>(part + ((size_t)z * M + m) * a.Cout + co);
+            s += p;
+        }
+        if (a.bias) s += *reinterpret_cast<const f32x4 *>(a.bias + co);
+        if (a.temb) {
+            const size_t b = m >> logHW;
+            s += *reinterpret_cast<const f32x4 *>(a.temb + b * a.temb_bstride + a.temb_off + co);
+        }
+        if (a.resid) {
+            const v4 rv = *reinterpret_cast<const v4 *>((const T *)a.resid + m * a.Cout + co);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += (float)rv[e];
+        }
+        v4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = (T)s[e];
+        *reinterpret_cast<v4 *>((T *)a.out + m * a.Cout + co) = ov;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_in: fp32 NCHW -> NHWC 16-bit, 3x3 pad 1, K = 9*Cin padded to KP (multiple of 16, <= 64)
+// one wave per 32 consecutive pixels; W16 is [C0][KP] 16-bit (k = ci*9 + ky*3 + kx)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv_in_kernel(const float *__restrict__ x, int Cx,
+                                                      const float *__restrict__ extra, int Ce,
+                                                      const T *__restrict__ W16, const float *__restrict__ bias,
+                                                      T *__restrict__ out, int B, int logH, int logW, int C0,
+                                                      int KP) {
+    using v8 = typename TT<T>::v8;
+    using v4 = typename TT<T>::v4;
+    const int l = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int H = 1 << logH, Wd = 1 << logW, HW = H * Wd;
+    const int M = B * HW;
+    const int m = wave * 32 + (l & 31);
+    if (wave * 32 >= M) return;
+    const int kh = l >> 5;
+    const int Cin = Cx + Ce;
+    const int mm = m < M ? m : M - 1;
+    const int xx = mm & (Wd - 1), yy = (mm >> logW) & (H - 1), b = mm >> (logW + logH);
+    const int nks = KP >> 4;
+    v8 bf[4];
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * s + 8 * kh + j;
+            float v = 0.f;
+            if (s < nks && k < 9 * Cin) {
+                const int ci = k / 9, t = k - ci * 9, dy = t / 3 - 1, dx = t - (dy + 1) * 3 - 1;
+                const int iy = yy + dy, ix = xx + dx;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)Wd)
+                    v = ci < Cx ? x[((size_t)b * Cx + ci) * HW + iy * Wd + ix]
+                                : extra[((size_t)b * Ce + (ci - Cx)) * HW + iy * Wd + ix];
+            }
+            bf[s][j] = (T)v;
+        }
+    }
+    for (int n0 = 0; n0 < C0; n0 += 32) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int s = 0; s < nks; ++s) {
+            const v8 af = *reinterpret_cast<const v8 *>(W16 + (size_t)(n0 + (l & 31)) * KP + 16 * s + 8 * kh);
+            acc = TT<T>::mfma(af, bf[s], acc);
+        }
+        if (m < M) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = n0 + 8 * g + 4 * kh;
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + co);
+                v4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = (T)(acc[4 * g + e] + bv[e]);
+                *reinterpret_cast<v4 *>(out + (size_t)m * C0 + co) = ov;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm
+// ------------------------------------------------------------------------------------------------
+// partial[((b*nslab + slab)*C + c)*2 + {0,1}] = sum / sum of squares over the slab's pixels
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T *__restrict__ x1, int C1, const T *__restrict__ x2,
+                                                       int C2, int HW, float *__restrict__ partial, int nslab) {
+    using v8 = typename TT<T>::v8;
+    __shared__ float red[256 * 16];
+    const int C = C1 + C2, CH = C >> 3;          // 16-byte chunks per pixel (<= 256)
+    const int slab = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int chunk = tid % CH, prow = tid / CH, RP = 256 / CH;
+    const int pps = HW / nslab;
+    float s[8], ss[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
+    const int c0 = chunk * 8;
+    const T *src;
+    int Cs;
+    if (c0 < C1) { src = x1 + c0; Cs = C1; } else { src = x2 + (c0 - C1); Cs = C2; }
+    if (prow < RP) {
+        for (int p = slab * pps + prow; p < (slab + 1) * pps; p += RP) {
+            const v8 v = *reinterpret_cast<const v8 *>(src + ((size_t)b * HW + p) * Cs);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)v[e];
+                s[e] += f;
+                ss[e] = fmaf(f, f, ss[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        red[tid * 16 + e] = s[e];
+        red[tid * 16 + 8 + e] = ss[e];
+    }
+    __syncthreads();
+    if (tid < CH) {
+        for (int r = 1; r < RP; ++r)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s[e] += red[(r * CH + tid) * 16 + e];
+                ss[e] += red[(r * CH + tid) * 16 + 8 + e];
+            }
+        float *o = partial + ((size_t)(b * nslab + slab) * C + tid * 8) * 2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[2 * e] = s[e];
+            o[2 * e + 1] = ss[e];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ partial, int nslab, int HW,
+                                                          int C, int groups, float eps,
+                                                          const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta,
+                                                          float *__restrict__ scale_shift) {
+    __shared__ double cs[1024], css[1024];
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double s = 0, q = 0;
+        for (int k = 0; k < nslab; ++k) {
+            const float *p = partial + ((size_t)(b * nslab + k) * C + c) * 2;
+            s += p[0];
+            q += p[1];
+        }
+        cs[c] = s;
+        css[c] = q;
+    }
+    __syncthreads();
+    const int Cg = C / groups;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g0 = (c / Cg) * Cg;
+        double s = 0, q = 0;
+        for (int k = 0; k < Cg; ++k) {
+            s += cs[g0 + k];
+            q += css[g0 + k];
+        }
+        const double n = (double)Cg * HW;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        var = var > 0 ? var : 0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = rstd * gamma[c];
+        scale_shift[((size_t)b * 2 + 0) * C + c] = sc;
+        scale_shift[((size_t)b * 2 + 1) * C + c] = beta[c] - (float)mean * sc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T *__restrict__ x1, int C1, const T *__restrict__ x2,
+                                                       int C2, const float *__restrict__ scale_shift, int HW,
+                                                       size_t total_chunks, int silu, T *__restrict__ out) {
+    using v8 = typename TT<T>::v8;
+    const int C = C1 + C2, CH = C >> 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_chunks;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / CH;
+        const int c0 = (int)(i - m * CH) * 8;
+        const size_t b = m / HW;
+        const v8 v = c0 < C1 ? *reinterpret_cast<const v8 *>(x1 + m * C1 + c0)
+                             : *reinterpret_cast<const v8 *>(x2 + m * C2 + (c0 - C1));
+        const float *sc = scale_shift + (b * 2) * C + c0;
+        const float *sh = sc + C;
+        const f32x4 s0 = *reinterpret_cast<const f32x4 *>(sc), s1 = *reinterpret_cast<const f32x4 *>(sc + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4 *>(sh), h1 = *reinterpret_cast<const f32x4 *>(sh + 4);
+        v8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = fmaf((float)v[e], e < 4 ? s0[e & 3] : s1[e & 3], e < 4 ? h0[e & 3] : h1[e & 3]);
+            if (silu) f = silu_f(f);
+            o[e] = (T)f;
+        }
+        *reinterpret_cast<v8 *>(out + m * C + c0) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention core: one thread per (sample, head, query)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attention_kernel(const T *__restrict__ qkv, T *__restrict__ out, int B, int Tn,
+                                                        int C) {
+    using v8 = typename TT<T>::v8;
+    const int heads = C >> 3;
+    const size_t total = (size_t)B * heads * Tn;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int h = (int)(idx % heads);
+    const size_t bt = idx / heads;          // b*T + tq
+    const size_t b = bt / Tn;
+    const v8 qv = *reinterpret_cast<const v8 *>(qkv + bt * 3 * C + h * 8);
+    float q[8], o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        q[e] = (float)qv[e] * 0.35355339059327373f;   // head_dim ** -0.5
+        o[e] = 0.f;
+    }
+    float mx = -INFINITY, den = 0.f;
+    for (int tk = 0; tk < Tn; ++tk) {
+        const T *row = qkv + (b * Tn + tk) * 3 * C + h * 8;
+        const v8 kv = *reinterpret_cast<const v8 *>(row + C);
+        const v8 vv = *reinterpret_cast<const v8 *>(row + 2 * C);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf(q[e], (float)kv[e], s);
+        const float nm = fmaxf(mx, s);
+        const float corr = __expf(mx - nm), p = __expf(s - nm);
+        den = den * corr + p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = o[e] * corr + p * (float)vv[e];
+        mx = nm;
+    }
+    const float inv = 1.0f / den;
+    v8 ov;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ov[e] = (T)(o[e] * inv);
+    *reinterpret_cast<v8 *>(out + bt * C + h * 8) = ov;
+}
+
+// ------------------------------------------------------------------------------------------------
+// time embedding MLP (fp32): act_emb = SiLU(W2 SiLU(W1 [cos|sin](t f) + b1) + b2)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void temb_mlp_kernel(const float *__restrict__ t, int C0, int D,
+                                                       const float *__restrict__ W1t, const float *__restrict__ b1,
+                                                       const float *__restrict__ W2t, const float *__restrict__ b2,
+                                                       T *__restrict__ act) {
+    __shared__ float emb[256];
+    __shared__ float h1[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float tv = t[b];
+    const int half = C0 >> 1;
+    for (int i = tid; i < C0; i += blockDim.x) {
+        const int k = i < half ? i : i - half;
+        const float f = expf(-9.210340371976184f * (float)k / (float)half);   // ln(10000)
+        const float ang = tv * f;
+        emb[i] = i < half ? cosf(ang) : sinf(ang);                            // flip_sin_to_cos
+    }
+    __syncthreads();
+    for (int n = tid; n < D; n += blockDim.x) {
+        float s = b1[n];
+        for (int k = 0; k < C0; ++k) s = fmaf(emb[k], W1t[(size_t)k * D + n], s);
+        h1[n] = s / (1.0f + expf(-s));
+    }
+    __syncthreads();
+    for (int n = tid; n < D; n += blockDim.x) {
+        float s = b2[n];
+        for (int k = 0; k < D; ++k) s = fmaf(h1[k], W2t[(size_t)k * D + n], s);
+        act[(size_t)b * D + n] = (T)(s / (1.0f + expf(-s)));
+    }
+}
+
+inline int ilog2(int v) {
+    int r = 0;
+    while ((1 << r) < v) ++r;
+    return r;
+}
+
+template <typename T, int WM, int WN, int TM, int TN, int EPI>
+int launch_conv_cfg(const ConvArgs &a, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int smem = 2 * (BM + BN) * 128;
+    int ksteps = 0;
+    for (int i = 0; i < a.nseg; ++i) ksteps += a.seg[i].taps * (a.seg[i].C / 64);
+    const int M = a.B * a.H * a.W;
+    const int ntm = ceil_div(M, BM), ntn = ceil_div(a.Cout, BN);
+    static bool attr = false;
+    if (!attr) {
+        BNDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm<T, WM, WN, TM, TN, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr = true;
+    }
+    dim3 grid(ntm * ntn, a.splitk > 1 ? a.splitk : 1);
+    hipLaunchKernelGGL((conv_igemm<T, WM, WN, TM, TN, EPI>), grid, dim3(256), smem, st, a, ksteps, ilog2(a.W),
+                       ilog2(a.H), ntm, ntn);
+    return launch_status("conv_igemm");
+}
+
+template <typename T>
+int launch_conv_t(int tile, int epi, const ConvArgs &a, hipStream_t st) {
+    if (tile == TILE_128x128) {
+        if (epi == EPI_NHWC16) return launch_conv_cfg<T, 2, 2, 2, 2, EPI_NHWC16>(a, st);
+        if (epi == EPI_F32_ROWS) return launch_conv_cfg<T, 2, 2, 2, 2, EPI_F32_ROWS>(a, st);
+    } else if (tile == TILE_128x32) {
+        if (epi == EPI_NCHW32) return launch_conv_cfg<T, 4, 1, 1, 1, EPI_NCHW32>(a, st);
+        if (epi == EPI_NHWC16) return launch_conv_cfg<T, 4, 1, 1, 1, EPI_NHWC16>(a, st);
+    }
+    set_error("launch_conv: unsupported tile/epilogue combination %d/%d", tile, epi);
+    return BNDM_E_ARG;
+}
+
+inline int grid_for(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, expr_f16, expr_bf16) ((dtype) == BNDM_DTYPE_F16 ? (expr_f16) : (expr_bf16))
+
+int launch_conv(int dtype, int tile, int epi, const ConvArgs &a, hipStream_t st) {
+    for (int i = 0; i < a.nseg; ++i)
+        if (a.seg[i].C % 64 != 0 || (a.seg[i].taps != 1 && a.seg[i].taps != 9)) {
+            set_error("launch_conv: segment %d has C=%d taps=%d", i, a.seg[i].C, a.seg[i].taps);
+            return BNDM_E_ARG;
+        }
+    if ((a.H & (a.H - 1)) || (a.W & (a.W - 1))) {
+        set_error("launch_conv: H, W must be powers of two (%d x %d)", a.H, a.W);
+        return BNDM_E_ARG;
+    }
+    return DISPATCH_T(dtype, launch_conv_t<_Float16>(tile, epi, a, st), launch_conv_t<__bf16>(tile, epi, a, st));
+}
+
+int launch_splitk_reduce(int dtype, const float *part, int splitk, const ConvArgs &a, hipStream_t st) {
+    const size_t total = (size_t)a.B * a.H * a.W * (a.Cout / 4);
+    const int lg = ilog2(a.H * a.W);
+    if (dtype == BNDM_DTYPE_F16)
+        hipLaunchKernelGGL(splitk_reduce_kernel<_Float16>, dim3(grid_for(total)), dim3(256), 0, st, part, splitk, a, lg);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, part, splitk, a, lg);
+    return launch_status("splitk_reduce");
+}
+
+int launch_conv_in(int dtype, const float *x, int Cx, const float *extra, int Ce, const void *W16, const float *bias,
+                   void *out, int B, int H, int W, int C0, int KP, hipStream_t st) {
+    const int M = B * H * W;
+    const int blocks = ceil_div(ceil_div(M, 32), 4);
+    if (dtype == BNDM_DTYPE_F16)
+        hipLaunchKernelGGL(conv_in_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, x, Cx, extra, Ce,
+                           (const _Float16 *)W16, bias, (_Float16 *)out, B, ilog2(H), ilog2(W), C0, KP);
+    else
+        hipLaunchKernelGGL(conv_in_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, x, Cx, extra, Ce,
+                           (const __bf16 *)W16, bias, (__bf16 *)out, B, ilog2(H), ilog2(W), C0, KP);
+    return launch_status("conv_in");
+}
+
+int gn_num_slabs(int HW) {
+    int n = HW / 256;
+    return n < 1 ? 1 : (n > 16 ? 16 : n);
+}
+
+int launch_gn_stats(int dtype, const void *x1, int C1, const void *x2, int C2, int B, int HW, float *partial,
+                    int nslab, hipStream_t st) {
+    if ((C1 + C2) / 8 > 256 || (C1 % 8) || (C2 % 8)) {
+        set_error("gn_stats: unsupported channel split %d+%d", C1, C2);
+        return BNDM_E_ARG;
+    }
+    dim3 grid(nslab, B);
+    if (dtype == BNDM_DTYPE_F16)
+        hipLaunchKernelGGL(gn_stats_kernel<_Float16>, grid, dim3(256), 0, st, (const _Float16 *)x1, C1,
+                           (const _Float16 *)x2, C2, HW, partial, nslab);
+    else
+        hipLaunchKernelGGL(gn_stats_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16 *)x1, C1,
+                           (const __bf16 *)x2, C2, HW, partial, nslab);
+    return launch_status("gn_stats");
+}
+
+int launch_gn_finalize(const float *partial, int nslab, int B, int HW, int C, int groups, float eps,
+                       const float *gamma, const float *beta, float *scale_shift, hipStream_t st) {
+    if (C > 1024 || C % groups) {
+        set_error("gn_finalize: C=%d groups=%d unsupported", C, groups);
+        return BNDM_E_ARG;
+    }
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, partial, nslab, HW, C, groups, eps, gamma,
+                       beta, scale_shift);
+    return launch_status("gn_finalize");
+}
+
+int launch_gn_apply(int dtype, const void *x1, int C1, const void *x2, int C2, const float *scale_shift, int B,
+                    int HW, int silu, void *out, hipStream_t st) {
+    const size_t total = (size_t)B * HW * ((C1 + C2) / 8);
+    if (dtype == BNDM_DTYPE_F16)
+        hipLaunchKernelGGL(gn_apply_kernel<_Float16>, dim3(grid_for(total)), dim3(256), 0, st, (const _Float16 *)x1,
+                           C1, (const _Float16 *)x2, C2, scale_shift, HW, total, silu, (_Float16 *)out);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, (const __bf16 *)x1, C1,
+                           (const __bf16 *)x2, C2, scale_shift, HW, total, silu, (__bf16 *)out);
+    return launch_status("gn_apply");
+}
+
+int launch_attention(int dtype, const void *qkv, void *out, int B, int T, int C, hipStream_t st) {
+    const size_t total = (size_t)B * (C / 8) * T;
+    const int blocks = (int)((total + 255) / 256);
+    if (dtype == BNDM_DTYPE_F16)
+        hipLaunchKernelGGL(attention_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, (const _Float16 *)qkv,
+                           (_Float16 *)out, B, T, C);
+    else
+        hipLaunchKernelGGL(attention_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, (const __bf16 *)qkv,
+                           (__bf16 *)out, B, T, C);
+    return launch_status("attention");
+}
+
+int launch_temb_mlp(int dtype, const float *t, int B, int C0, int D, const float *W1t, const float *b1,
+                    const float *W2t, const float *b2, void *act_emb16, hipStream_t st) {
+    if (C0 > 256 || D > 1024) {
+        set_error("temb_mlp: C0=%d D=%d unsupported", C0, D);
+        return BNDM_E_ARG;
+    }
+    if (dtype == BNDM_DTYPE_F16)
+        hipLaunchKernelGGL(temb_mlp_kernel<_Float16>, dim3(B), dim3(256), 0, st, t, C0, D, W1t, b1, W2t, b2,
+                           (_Float16 *)act_emb16);
+    else
+        hipLaunchKernelGGL(temb_mlp_kernel<__bf16>, dim3(B), dim3(256), 0, st, t, C0, D, W1t, b1, W2t, b2,
+                           (__bf16 *)act_emb16);
+    return launch_status("temb_mlp");
+}
+
+}  // namespace bndm

@@ -1,0 +1,69 @@
+// Launch interface of the UNet kernels (csrc/unet_kernels.hip), used by the engine.
+// Activations are NHWC 16-bit (f16 or bf16, chosen per handle); statistics, biases, time
+// embeddings and accumulators are fp32.
+#pragma once
+#include "common.hpp"
+
+namespace bndm {
+
+constexpr int CONV_MAX_SEG = 4;
+
+// One K-segment of an implicit-GEMM convolution: a source tensor read with 3x3 (pad 1) or 1x1 taps.
+// Several segments express torch.cat([h, skip], 1) feeding conv1, and conv2 + the 1x1 conv_shortcut
+// of a ResnetBlock2D accumulated into the same output tile.
+struct ConvSeg {
+    const void *src;  // NHWC 16-bit, [B, Hs, Ws, C]
+    int C;            // channels (multiple of 64)
+    int taps;         // 9 or 1
+    int up;           // 1: src is at half the output resolution (nearest-2x Upsample2D fused)
+};
+
+struct ConvArgs {
+    ConvSeg seg[CONV_MAX_SEG];
+    int nseg;
+    const void *Wgt;     // [Cout_pad][Ktot] 16-bit, k ordered segment -> tap -> channel
+    const float *bias;   // [Cout] or nullptr
+    const float *temb;   // fp32 [*, temb_stride]; adds temb[b*temb_bstride + temb_off + co]
+    int temb_bstride, temb_off;
+    const void *resid;   // NHWC 16-bit [M, Cout] or nullptr
+    void *out;           // layout per epilogue
+    int B, H, W;         // output spatial size (powers of two)
+    int stride;          // 1, or 2 for Downsample2D (segments are then [B, 2H, 2W, C])
+    int Cout;            // real output channels
+    int Ktot;
+    int splitk;          // >1: fp32 partial slabs [splitk][M][Cout] into `out`, no bias
+    const void *zeros;   // >= 16 bytes of zeros (source of padding taps)
+};
+
+enum ConvEpilogue { EPI_NHWC16 = 0, EPI_F32_ROWS = 1, EPI_NCHW32 = 2 };
+enum ConvTile { TILE_128x128 = 0, TILE_128x32 = 1 };
+
+int launch_conv(int dtype, int tile, int epi, const ConvArgs &a, hipStream_t st);
+
+// sum split-K slabs + bias + temb + residual -> NHWC 16-bit
+int launch_splitk_reduce(int dtype, const float *part, int splitk, const ConvArgs &a, hipStream_t st);
+
+// conv_in: fp32 NCHW sample (+ optional extra fp32 NCHW tensor concatenated on channels) -> NHWC 16-bit
+// W16 is [C0][KP] 16-bit with k = ci*9 + ky*3 + kx, zero-padded to KP (multiple of 16, <= 64)
+int launch_conv_in(int dtype, const float *x, int Cx, const float *extra, int Ce, const void *W16,
+                   const float *bias, void *out, int B, int H, int W, int C0, int KP, hipStream_t st);
+
+// GroupNorm(32) statistics of cat(x1, x2) -> per-(sample, channel) scale/shift
+//   y = x * scale[b][c] + shift[b][c]  ==  (x - mean_g) * rstd_g * gamma_c + beta_c
+int launch_gn_stats(int dtype, const void *x1, int C1, const void *x2, int C2, int B, int HW, float *partial,
+                    int nslab, hipStream_t st);
+int launch_gn_finalize(const float *partial, int nslab, int B, int HW, int C, int groups, float eps,
+                       const float *gamma, const float *beta, float *scale_shift /*[B][2][C]*/, hipStream_t st);
+int launch_gn_apply(int dtype, const void *x1, int C1, const void *x2, int C2, const float *scale_shift, int B,
+                    int HW, int silu, void *out, hipStream_t st);
+
+// softmax(q k^T / sqrt(8)) v per (sample, head of 8 channels); qkv [B*T][3C] -> out [B*T][C]
+int launch_attention(int dtype, const void *qkv, void *out, int B, int T, int C, hipStream_t st);
+
+// Timesteps(128, flip_sin_to_cos) -> Linear -> SiLU -> Linear -> SiLU, fp32; writes 16-bit [B][D]
+int launch_temb_mlp(int dtype, const float *t, int B, int C0, int D, const float *W1t /*[C0][D]*/, const float *b1,
+                    const float *W2t /*[D][D]*/, const float *b2, void *act_emb16, hipStream_t st);
+
+int gn_num_slabs(int HW);
+
+}  // namespace bndm

@@ -1,0 +1,301 @@
+"""``UNet2DModel`` with the diffusers call surface the reference uses, running on the HIP engine.
+
+The reference builds ``diffusers.UNet2DModel(block_out_channels=..., down_block_types=...,
+up_block_types=..., in_channels=..., out_channels=..., act_fn='silu', add_attention=True)``
+(iadb_bn.py:282, utils.py:84, ddim_diffusers.py:378, latent_iadb_bn_diffusers.py:364) and calls
+``model(x, t, return_dict=False)[0]`` (iadb_bn.py:319) or ``model(x, t).sample``
+(ddim_diffusers.py:679).  This class keeps that surface:
+
+* parameters live in a module tree with diffusers' state-dict key names, so ``load_state_dict``,
+  ``state_dict``, ``torch.save/load`` of ``model.ckpt`` (iadb_bn.py:714,1028), ``.to(device)`` and
+  ``.eval()`` behave as with the original;
+* ``forward`` hands the fp32 NCHW sample and the timesteps to ``bndm_unet_forward``
+  (csrc/unet_engine.hip); there is no PyTorch compute path behind it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+import os
+from dataclasses import dataclass
+
+import torch
+from torch import nn
+
+from . import _lib
+
+DTYPE_F16, DTYPE_BF16 = 0, 1
+
+
+@dataclass
+class UNet2DOutput:
+    sample: torch.Tensor
+
+
+class _P(nn.Module):
+    """weight/bias holder (Conv2d, Linear or GroupNorm parameters)."""
+
+    def __init__(self, wshape, kind):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(wshape), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(wshape[0]), requires_grad=False)
+        self.kind = kind
+
+    def reset(self, gen):
+        if self.kind == "norm":
+            self.weight.fill_(1.0)
+            self.bias.zero_()
+        else:  # torch's default Conv2d/Linear init: U(+-1/sqrt(fan_in)) for weight and bias
+            fan_in = self.weight[0].numel()
+            bound = 1.0 / math.sqrt(fan_in)
+            self.weight.copy_((torch.rand(self.weight.shape, generator=gen) * 2 - 1) * bound)
+            self.bias.copy_((torch.rand(self.bias.shape, generator=gen) * 2 - 1) * bound)
+
+
+def _conv(ci, co, k):
+    return _P((co, ci, k, k), "conv")
+
+
+def _lin(ci, co):
+    return _P((co, ci), "linear")
+
+
+def _norm(c):
+    return _P((c,), "norm")
+
+
+class _Resnet(nn.Module):
+    def __init__(self, ci, co, temb):
+        super().__init__()
+        self.norm1 = _norm(ci)
+        self.conv1 = _conv(ci, co, 3)
+        self.time_emb_proj = _lin(temb, co)
+        self.norm2 = _norm(co)
+        self.conv2 = _conv(co, co, 3)
+        if ci != co:
+            self.conv_shortcut = _conv(ci, co, 1)
+
+
+class _Attn(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.group_norm = _norm(c)
+        self.to_q = _lin(c, c)
+        self.to_k = _lin(c, c)
+        self.to_v = _lin(c, c)
+        self.to_out = nn.ModuleList([_lin(c, c)])
+
+
+class _Sampler(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = _conv(c, c, 3)
+
+
+class _Block(nn.Module):
+    def __init__(self, resnets, attns, sampler_name, sampler):
+        super().__init__()
+        self.resnets = nn.ModuleList(resnets)
+        if attns:
+            self.attentions = nn.ModuleList(attns)
+        if sampler is not None:
+            setattr(self, sampler_name, nn.ModuleList([sampler]))
+
+
+class _TimeEmbedding(nn.Module):
+    def __init__(self, ci, d):
+        super().__init__()
+        self.linear_1 = _lin(ci, d)
+        self.linear_2 = _lin(d, d)
+
+
+class UNet2DModel(nn.Module):
+    """Constructor arguments follow diffusers; only what the reference varies is configurable."""
+
+    def __init__(self, sample_size=None, in_channels=3, out_channels=3, center_input_sample=False,
+                 time_embedding_type="positional", freq_shift=0, flip_sin_to_cos=True,
+                 down_block_types=("DownBlock2D", "AttnDownBlock2D", "AttnDownBlock2D", "AttnDownBlock2D"),
+                 up_block_types=("AttnUpBlock2D", "AttnUpBlock2D", "AttnUpBlock2D", "UpBlock2D"),
+                 block_out_channels=(224, 448, 672, 896), layers_per_block=2, mid_block_scale_factor=1,
+                 downsample_padding=1, act_fn="silu", attention_head_dim=8, norm_num_groups=32, norm_eps=1e-5,
+                 add_attention=True, dtype="f16", seed=None, **unused):
+        super().__init__()
+        if act_fn != "silu":
+            raise NotImplementedError(f"act_fn={act_fn!r}: the HIP path implements SiLU (every shipped script)")
+        if attention_head_dim != 8 or norm_num_groups != 32 or not add_attention or center_input_sample \
+                or time_embedding_type != "positional" or not flip_sin_to_cos or freq_shift != 0:
+            raise NotImplementedError("only the diffusers defaults the reference relies on are implemented")
+        if len(down_block_types) != len(block_out_channels) or len(up_block_types) != len(block_out_channels):
+            raise ValueError("block type lists must match block_out_channels")
+        for t in tuple(down_block_types) + tuple(up_block_types):
+            if t not in ("DownBlock2D", "AttnDownBlock2D", "UpBlock2D", "AttnUpBlock2D"):
+                raise NotImplementedError(t)
+        boc = tuple(int(c) for c in block_out_channels)
+        n = len(boc)
+        self.config = dict(sample_size=sample_size, in_channels=in_channels, out_channels=out_channels,
+                           down_block_types=tuple(down_block_types), up_block_types=tuple(up_block_types),
+                           block_out_channels=boc, layers_per_block=layers_per_block, act_fn=act_fn,
+                           attention_head_dim=8, norm_num_groups=32, norm_eps=1e-5, add_attention=True)
+        self.compute_dtype = dtype
+        temb = boc[0] * 4
+        self.conv_in = _conv(in_channels, boc[0], 3)
+        self.time_embedding = _TimeEmbedding(boc[0], temb)
+        downs, out_c = [], boc[0]
+        for i in range(n):
+            in_c, out_c = out_c, boc[i]
+            attn = down_block_types[i] == "AttnDownBlock2D"
+            res = [_Resnet(in_c if j == 0 else out_c, out_c, temb) for j in range(layers_per_block)]
+            att = [_Attn(out_c) for _ in range(layers_per_block)] if attn else []
+            downs.append(_Block(res, att, "downsamplers", _Sampler(out_c) if i != n - 1 else None))
+        self.down_blocks = nn.ModuleList(downs)
+        self.mid_block = _Block([_Resnet(boc[-1], boc[-1], temb), _Resnet(boc[-1], boc[-1], temb)],
+                                [_Attn(boc[-1])], "", None)
+        ups, rev, out_c = [], boc[::-1], boc[-1]
+        for i in range(n):
+            prev, out_c = out_c, rev[i]
+            in_c = rev[min(i + 1, n - 1)]
+            attn = up_block_types[i] == "AttnUpBlock2D"
+            nl = layers_per_block + 1
+            res = [_Resnet((prev if j == 0 else out_c) + (in_c if j == nl - 1 else out_c), out_c, temb)
+                   for j in range(nl)]
+            att = [_Attn(out_c) for _ in range(nl)] if attn else []
+            ups.append(_Block(res, att, "upsamplers", _Sampler(out_c) if i != n - 1 else None))
+        self.up_blocks = nn.ModuleList(ups)
+        self.conv_norm_out = _norm(boc[0])
+        self.conv_out = _conv(boc[0], out_channels, 3)
+        gen = torch.Generator().manual_seed(seed) if seed is not None else None
+        with torch.no_grad():
+            for m in self.modules():
+                if isinstance(m, _P):
+                    m.reset(gen)
+        self._engine = None
+        self._engine_key = None
+
+    # ------------------------------------------------------------------ engine management
+    def _param_version(self):
+        return tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
+
+    def release_engine(self):
+        if self._engine is not None:
+            _lib.load().bndm_unet_destroy(self._engine)
+            self._engine = None
+            self._engine_key = None
+
+    def __del__(self):
+        try:
+            self.release_engine()
+        except Exception:
+            pass
+
+    def _ensure_engine(self, B, res, device):
+        key = (self._param_version(), res, self.compute_dtype, device.index)
+        if self._engine is not None and self._engine_key is not None and self._engine_key[0] == key \
+                and self._engine_key[1] >= B:
+            return self._engine
+        self.release_engine()
+        lib = _lib.load()
+        cfg = _lib.UNetConfig()
+        c = self.config
+        boc = c["block_out_channels"]
+        cfg.in_channels, cfg.out_channels, cfg.resolution = c["in_channels"], c["out_channels"], res
+        cfg.num_levels = len(boc)
+        for i, v in enumerate(boc):
+            cfg.block_out_channels[i] = v
+            cfg.down_attn[i] = int(c["down_block_types"][i] == "AttnDownBlock2D")
+            cfg.up_attn[i] = int(c["up_block_types"][i] == "AttnUpBlock2D")
+        cfg.layers_per_block = c["layers_per_block"]
+        cfg.dtype = {"f16": DTYPE_F16, "fp16": DTYPE_F16, "bf16": DTYPE_BF16}[self.compute_dtype]
+        max_batch = max(B, 1)
+        cfg.max_batch = max_batch
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.bndm_unet_create(C.byref(h), C.byref(cfg)), "bndm_unet_create")
+            try:
+                sd = self.state_dict()
+                n = lib.bndm_unet_num_params(h)
+                name = C.create_string_buffer(200)
+                numel = C.c_int64()
+                seen = set()
+                for i in range(n):
+                    _lib.check(lib.bndm_unet_param_info(h, i, name, 200, C.byref(numel)), "param_info")
+                    k = name.value.decode()
+                    if k not in sd:
+                        raise KeyError(f"state dict lacks '{k}'")
+                    t = sd[k].detach().to("cpu", torch.float32).contiguous()
+                    _lib.check(lib.bndm_unet_load_param(h, name.value, C.c_void_p(t.data_ptr()), t.numel()),
+                               f"load_param({k})")
+                    seen.add(k)
+                extra = set(sd) - seen
+                if extra:
+                    raise KeyError(f"unexpected keys in state dict: {sorted(extra)[:4]}...")
+                _lib.check(lib.bndm_unet_finalize(h), "bndm_unet_finalize")
+            except Exception:
+                lib.bndm_unet_destroy(h)
+                raise
+        self._engine, self._engine_key = h, (key, max_batch)
+        return h
+
+    # ------------------------------------------------------------------ diffusers-style API
+    def _timesteps(self, timestep, B, device):
+        t = timestep
+        if not torch.is_tensor(t):
+            t = torch.tensor([t], dtype=torch.float32, device=device)
+        elif t.dim() == 0:
+            t = t[None]
+        t = t.to(device=device, dtype=torch.float32)
+        return (t * torch.ones(B, dtype=torch.float32, device=device)).contiguous()
+
+    @torch.no_grad()
+    def forward(self, sample, timestep, class_labels=None, return_dict=True):
+        _lib.require_gpu(sample, "UNet2DModel.forward(sample)")
+        if sample.dtype != torch.float32:
+            sample = sample.float()
+        sample = sample.contiguous()
+        B, Cin, H, W = sample.shape
+        if Cin != self.config["in_channels"] or H != W:
+            raise ValueError(f"sample shape {tuple(sample.shape)} does not fit in_channels={self.config['in_channels']}")
+        h = self._ensure_engine(B, H, sample.device)
+        t = self._timesteps(timestep, B, sample.device)
+        out = torch.empty((B, self.config["out_channels"], H, W), dtype=torch.float32, device=sample.device)
+        rc = _lib.load().bndm_unet_forward(h, C.c_void_p(sample.data_ptr()), C.c_void_p(t.data_ptr()),
+                                           C.c_void_p(out.data_ptr()), B, _lib.current_stream_ptr())
+        _lib.check(rc, "bndm_unet_forward")
+        if not return_dict:
+            return (out,)
+        return UNet2DOutput(sample=out)
+
+    # ------------------------------------------------------------------ on-disk formats
+    def save_pretrained(self, directory, safe_serialization=True):
+        os.makedirs(directory, exist_ok=True)
+        cfg = dict(self.config, _class_name="UNet2DModel")
+        with open(os.path.join(directory, "config.json"), "w") as f:
+            json.dump(cfg, f, indent=2)
+        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
+        if safe_serialization:
+            from safetensors.torch import save_file
+            save_file(sd, os.path.join(directory, "diffusion_pytorch_model.safetensors"))
+        else:
+            torch.save(sd, os.path.join(directory, "diffusion_pytorch_model.bin"))
+
+    @classmethod
+    def from_pretrained(cls, directory, use_safetensors=True, **kw):
+        """UNet2DModel.from_pretrained(out_dir + '/unet', use_safetensors=True) (ddim_diffusers.py:642)."""
+        with open(os.path.join(directory, "config.json")) as f:
+            cfg = json.load(f)
+        keep = ("sample_size", "in_channels", "out_channels", "down_block_types", "up_block_types",
+                "block_out_channels", "layers_per_block", "act_fn")
+        model = cls(**{k: cfg[k] for k in keep if k in cfg}, **kw)
+        st = os.path.join(directory, "diffusion_pytorch_model.safetensors")
+        if use_safetensors and os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(directory, "diffusion_pytorch_model.bin"), map_location="cpu")
+        model.load_state_dict(sd)
+        return model
+
+
+def unwrap(model):
+    """torch.nn.DataParallel(model) (iadb_bn.py:716) -> the wrapped module."""
+    return model.module if isinstance(model, nn.DataParallel) else model
