@@ -41,7 +41,6 @@ def cpu_baseline(nb_steps, seed=0):
     from oracle import sampler_oracle as SO
     from oracle import unet_oracle as UO
     from bndm_amd.synth import formula_factor
-    torch.set_num_threads(os.cpu_count() or 1)
     B = 4
     cfg = UO.make_config(64, 3, 6)
     sd = UO.init_params(cfg, seed=seed)
@@ -64,6 +63,21 @@ def cpu_baseline(nb_steps, seed=0):
         d = model(x, a1)[0]
         return x + (a1 - a0).view(-1, 1, 1, 1) * d[:, :3] + (g1 - g0).view(-1, 1, 1, 1) * d[:, 3:]
 
+    # thread count: all host cores oversubscribe MKL-DNN on big boxes (256 threads: >50x slower than
+    # 32); calibrate on one step per candidate and keep the fastest
+    ncpu = os.cpu_count() or 1
+    best = None
+    for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(nt)
+        one_step(x, nb_steps - 1)                    # warm-up at this thread count
+        t0 = time.perf_counter()
+        one_step(x, nb_steps - 1)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, nt)
+        if dt > 20:
+            break
+    torch.set_num_threads(best[1])
     x = one_step(x, nb_steps - 1)                    # warm-up
     n_timed = 3
     t0 = time.perf_counter()
@@ -87,6 +101,7 @@ def main():
     ap.add_argument("--nb_steps", type=int, default=250, help="denoising steps per image")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-only", action="store_true", help="skip the timed passes; only the per-kernel profile")
     args = ap.parse_args()
 
     from bndm_amd import _lib
@@ -124,16 +139,18 @@ def main():
         u8 = export_u8(x, "trunc")
         return gather_images(u8, dst=0)
 
-    for _ in range(args.warmup):
-        one_pass()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_pass()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = max_over_ranks(time.perf_counter() - t0, device=dev)
+    elapsed = float("nan")
+    if not args.profile_only:
+        for _ in range(args.warmup):
+            one_pass()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = one_pass()
+        barrier()
+        torch.cuda.synchronize()
+        elapsed = max_over_ranks(time.perf_counter() - t0, device=dev)
 
     # ---- dominant kernel (conv_igemm) timed with HIP events on the launch stream ---------------------
     roof = None

@@ -73,6 +73,7 @@ struct Op {
     int cls;
     double flops_per_sample;   // algorithmic 2*MAC per batch element (convs only)
     std::function<int(RunCtx &)> run;
+    std::string name;
 };
 
 }  // namespace
@@ -273,11 +274,15 @@ struct Builder {
         return Act{slot, C, H, W};
     }
 
-    void push(int cls, double flops, std::function<int(RunCtx &)> fn) { h->ops.push_back(Op{cls, flops, std::move(fn)}); }
+    std::string cur_name;
+    void push(int cls, double flops, std::function<int(RunCtx &)> fn) {
+        h->ops.push_back(Op{cls, flops, std::move(fn), cur_name});
+    }
 
     // GroupNorm(32) of cat(x1, x2) followed by optional SiLU -> out
     void group_norm(const Act &x1, const Act *x2, const std::string &pname, bool silu, const Act &out) {
         bndm_unet *hh = h;
+        cur_name = S("gn   %-44s C=%-4d %dx%d", pname.c_str(), x1.C + (x2 ? x2->C : 0), x1.H, x1.W);
         const int C1 = x1.C, C2 = x2 ? x2->C : 0, C = C1 + C2, HW = x1.H * x1.W;
         const int nslab = gn_num_slabs(HW);
         const float *gamma, *beta;
@@ -305,8 +310,9 @@ struct Builder {
 
     // generic NHWC16 conv: out = sum over segments + bias (+temb) (+resid)
     void conv(const std::vector<SegIn> &ins, const void *Wp, int Ktot, const float *bias, int temb_off,
-              const Act *resid, const Act &out, int stride) {
+              const Act *resid, const Act &out, int stride, const std::string &label = "") {
         bndm_unet *hh = h;
+        cur_name = S("conv %-44s K=%-5d N=%-4d %dx%d", label.c_str(), Ktot, out.C, out.H, out.W);
         ConvArgs a{};
         a.nseg = (int)ins.size();
         std::vector<int> slots;
@@ -402,7 +408,7 @@ struct Builder {
         rc = pack_conv_weight(h, {WSeg{&h->hp(name + ".conv1.weight"), Cin, 0, Cin, 9}}, Cout, 128, &W1, &K1);
         if (rc) return x1;
         Act h1 = scratch(h->s_h1, Cout, H, W);
-        conv({SegIn{y1, 9, 0}}, W1, K1, bias_of(name + ".conv1"), temb_off, nullptr, h1, 1);
+        conv({SegIn{y1, 9, 0}}, W1, K1, bias_of(name + ".conv1"), temb_off, nullptr, h1, 1, name + ".conv1");
         Act y2 = scratch(h->s_y2, Cout, H, W);
         group_norm(h1, nullptr, name + ".norm2", true, y2);
         if (rc) return x1;
@@ -420,11 +426,11 @@ struct Builder {
             }
             rc = pack_conv_weight(h, ws, Cout, 128, &W2, &K2);
             if (rc) return x1;
-            conv(ins, W2, K2, bias_of(name + ".conv2", &sc), -1, nullptr, out, 1);
+            conv(ins, W2, K2, bias_of(name + ".conv2", &sc), -1, nullptr, out, 1, name + ".conv2+sc");
         } else {
             rc = pack_conv_weight(h, {WSeg{&h->hp(name + ".conv2.weight"), Cout, 0, Cout, 9}}, Cout, 128, &W2, &K2);
             if (rc) return x1;
-            conv({SegIn{y2, 9, 0}}, W2, K2, bias_of(name + ".conv2"), -1, &x1, out, 1);
+            conv({SegIn{y2, 9, 0}}, W2, K2, bias_of(name + ".conv2"), -1, &x1, out, 1, name + ".conv2");
         }
         return out;
     }
@@ -450,9 +456,10 @@ struct Builder {
         const float *bq;
         if ((rc = upload_f32(h, bcat, &bq))) return x;
         Act qkv = scratch(h->s_qkv, 3 * C, H, W);
-        conv({SegIn{yn, 1, 0}}, Wqkv, Kq, bq, -1, nullptr, qkv, 1);
+        conv({SegIn{yn, 1, 0}}, Wqkv, Kq, bq, -1, nullptr, qkv, 1, name + ".qkv");
         Act att = scratch(h->s_att, C, H, W);
         const int sq = qkv.slot, sa = att.slot;
+        cur_name = S("attn %s T=%d", name.c_str(), T);
         push(OPC_OTHER, 0, [=](RunCtx &r) {
             return launch_attention(hh->dtype(), hh->P(sq), hh->P(sa), r.B, T, C, r.st);
         });
@@ -461,7 +468,7 @@ struct Builder {
         rc = pack_conv_weight(h, {WSeg{&h->hp(name + ".to_out.0.weight"), C, 0, C, 1}}, C, 128, &Wo, &Ko);
         if (rc) return x;
         Act out = new_act(C, H, W);
-        conv({SegIn{att, 1, 0}}, Wo, Ko, bias_of(name + ".to_out.0"), -1, &x, out, 1);
+        conv({SegIn{att, 1, 0}}, Wo, Ko, bias_of(name + ".to_out.0"), -1, &x, out, 1, name + ".to_out");
         return out;
     }
 
@@ -471,7 +478,7 @@ struct Builder {
         rc = pack_conv_weight(h, {WSeg{&h->hp(name + ".weight"), x.C, 0, x.C, 9}}, x.C, 128, &Wp, &K);
         if (rc) return x;
         Act out = down ? new_act(x.C, x.H / 2, x.W / 2) : new_act(x.C, x.H * 2, x.W * 2);
-        conv({SegIn{x, 9, down ? 0 : 1}}, Wp, K, bias_of(name), -1, nullptr, out, down ? 2 : 1);
+        conv({SegIn{x, 9, down ? 0 : 1}}, Wp, K, bias_of(name), -1, nullptr, out, down ? 2 : 1, name);
         return out;
     }
 
@@ -516,12 +523,14 @@ struct Builder {
             if ((rc = upload_f32(h, w2t, &dw2))) return rc;
             if ((rc = upload_f32(h, h->hp("time_embedding.linear_1.bias"), &db1))) return rc;
             if ((rc = upload_f32(h, h->hp("time_embedding.linear_2.bias"), &db2))) return rc;
+            cur_name = "temb_mlp";
             push(OPC_OTHER, 0, [=](RunCtx &r) {
                 return launch_temb_mlp(hh->dtype(), r.timesteps, r.B, C0, D, dw1, db1, dw2, db2, hh->P(hh->s_actemb),
                                        r.st);
             });
         }
         const size_t temb_proj_op = h->ops.size();
+        cur_name = "conv time_emb_proj (all resnets)";
         push(OPC_CONV, 0, [](RunCtx &) { return 0; });   // placeholder: all time_emb_proj as one GEMM
 
         // ---- conv_in ------------------------------------------------------------------------------
@@ -541,6 +550,7 @@ struct Builder {
             const float *db = bias_of("conv_in");
             if (rc) return rc;
             const int so = x.slot;
+            cur_name = "conv_in";
             push(OPC_OTHER, 0, [=](RunCtx &r) {
                 const int Ce = r.extra ? Cin / 2 : 0;     // conditional sampler: x and x_c have equal channels
                 return launch_conv_in(hh->dtype(), r.sample, Cin - Ce, r.extra, Ce, dW, db, hh->P(so), r.B, R, R, C0,
@@ -613,6 +623,7 @@ struct Builder {
             a.splitk = 1;
             a.zeros = h->zeros;
             const int sy = y.slot;
+            cur_name = S("conv conv_out K=%d N=%d %dx%d", K, c.out_channels, R, R);
             push(OPC_CONV, 2.0 * 9 * C0 * c.out_channels * R * R, [=](RunCtx &r) {
                 ConvArgs cc = a;
                 cc.seg[0].src = hh->P(sy);
@@ -652,7 +663,7 @@ struct Builder {
                                           cc.B = r.B;
                                           cc.out = hh->P(hh->s_tp);
                                           return launch_conv(hh->dtype(), TILE_128x128, EPI_F32_ROWS, cc, r.st);
-                                      }};
+                                      }, "conv time_emb_proj (all resnets)"};
         }
         return 0;
     }
@@ -863,18 +874,30 @@ extern "C" int bndm_unet_profile(bndm_unet *h, const float *sample, const float 
     // (2) per-op events, accumulated by class
     double conv_ms = 0, conv_flops = 0;
     int conv_launches = 0;
+    std::vector<double> op_ms(nops, 0.0);
     for (int i = 0; i < iters; ++i) {
         RunCtx rp{B, st, sample, nullptr, timesteps, out};
         rp.prof = true;
         rp.ev = &ev;
         if ((rc = run_forward(h, rp))) return rc;
         BNDM_CHECK_HIP(hipStreamSynchronize(st));
-        for (size_t k = 0; k < nops; ++k)
-            if (h->ops[k].cls == OPC_CONV) {
-                float m = 0;
-                BNDM_CHECK_HIP(hipEventElapsedTime(&m, ev[2 * k], ev[2 * k + 1]));
-                conv_ms += m;
+        for (size_t k = 0; k < nops; ++k) {
+            float m = 0;
+            BNDM_CHECK_HIP(hipEventElapsedTime(&m, ev[2 * k], ev[2 * k + 1]));
+            op_ms[k] += m;
+            if (h->ops[k].cls == OPC_CONV) conv_ms += m;
+        }
+    }
+    if (const char *dump = getenv("BNDM_PROFILE_DUMP")) {
+        FILE *f = fopen(dump, "w");
+        if (f) {
+            for (size_t k = 0; k < nops; ++k) {
+                const double ms_k = op_ms[k] / iters, fl = h->ops[k].flops_per_sample * B;
+                fprintf(f, "%3zu %8.4f ms %8.1f TF/s  %s\n", k, ms_k, ms_k > 0 ? fl / (ms_k * 1e-3) / 1e12 : 0.0,
+                        h->ops[k].name.c_str());
             }
+            fclose(f);
+        }
     }
     for (size_t k = 0; k < nops; ++k)
         if (h->ops[k].cls == OPC_CONV) {

@@ -67,3 +67,50 @@ int launch_temb_mlp(int dtype, const float *t, int B, int C0, int D, const float
 int gn_num_slabs(int HW);
 
 }  // namespace bndm
+
+// ------------------------------------------------------------------------------------------------
+// Fused 3x3 convolution (stride 1) for the high-resolution, FLOP-dominant layers.
+//   prologue : GroupNorm scale/shift (+SiLU) applied while the (TH+2)x18 input halo patch of a
+//              64-channel chunk is staged into LDS -- once per element, not once per tap;
+//   main loop: 9 taps read MFMA fragments from the same LDS patch at shifted pixel offsets, weight
+//              tiles streamed by global_load_lds (double-buffered);
+//   epilogue : bias + time embedding + residual, tile staged through LDS for full-row stores, and
+//              per-(sample, channel) sum / sum-of-squares of the stored values for the next GroupNorm.
+// ------------------------------------------------------------------------------------------------
+namespace bndm {
+
+struct FusedSeg {
+    const void *src;  // NHWC 16-bit [B, Hs, Ws, C]
+    int C;            // multiple of 64
+    int taps;         // 9 (3x3, pad 1) or 1 (1x1 conv_shortcut on the raw tensor)
+    int up;           // source at half resolution (nearest-2x upsample)
+    int ss_off;       // channel offset into the scale/shift table, or -1: no normalisation
+};
+
+struct FusedArgs {
+    FusedSeg seg[CONV_MAX_SEG];
+    int nseg;
+    const float *ss;     // [B][2][ssC] scale / shift, nullptr when no segment is normalised
+    int ssC;
+    int silu;
+    const void *Wgt;     // same packing as ConvArgs: [Cout_pad][Ktot], k = segment -> tap -> channel
+    int Ktot;
+    const float *bias;
+    const float *temb;
+    int temb_bstride, temb_off;
+    const void *resid;
+    void *out;           // NHWC 16-bit
+    float *stats;        // [B][tiles_per_sample][Cout][2] or nullptr
+    int B, H, W, Cout;
+};
+
+// TH = 16 (256-pixel tiles) or 8 (128-pixel tiles); W must be a multiple of 16, H of TH
+int launch_conv_fused(int dtype, int TH, const FusedArgs &a, hipStream_t st);
+int conv_fused_tiles_per_sample(int TH, int H, int W);
+
+// two-source variant of gn_finalize: statistics of cat(x1, x2) from per-tensor partial sums
+int launch_gn_finalize2(const float *p1, int nslab1, int C1, const float *p2, int nslab2, int C2, int B, int HW,
+                        int groups, float eps, const float *gamma, const float *beta, float *scale_shift,
+                        hipStream_t st);
+
+}  // namespace bndm
