@@ -62,6 +62,9 @@ struct RunCtx {
     const float *extra;
     const float *timesteps;
     float *out;
+    // time-embedding projections precomputed for the whole schedule (sampler loops): row of this step,
+    // shared by every sample (batch stride 0); nullptr -> computed per forward from `timesteps`
+    const float *tp_row = nullptr;
     // profiling
     bool prof = false;
     std::vector<hipEvent_t> *ev = nullptr;
@@ -92,6 +95,11 @@ struct bndm_unet {
     std::vector<Op> ops;
     int ntemb = 0;                     // total time_emb_proj columns
     void *zeros = nullptr;
+    // per-schedule time-embedding table (K10): [cap][ntemb] fp32, [cap] fp32 t, [cap][temb_dim] 16-bit
+    float *tp_table = nullptr, *t_steps = nullptr;
+    void *act_steps = nullptr;
+    int tp_cap = 0;
+    std::function<int(int, const float *, void *, float *, hipStream_t)> temb_table_fn;
 
     // fixed scratch slots
     int s_y = -1, s_h1 = -1, s_y2 = -1, s_part = -1, s_ss = -1, s_qkv = -1, s_att = -1, s_splitk = -1;
@@ -261,10 +269,19 @@ int pack_conv_weight(bndm_unet *h, const std::vector<WSeg> &segs, int Cout, int 
 // ------------------------------------------------------------------------------------------------
 // graph construction
 // ------------------------------------------------------------------------------------------------
+struct StatRef {
+    int pslot = -1;   // buffer slot of partial sums [B][nslab][C][2]
+    int nslab = 0;
+};
+
 struct Builder {
     bndm_unet *h;
     int rc = 0;
     int temb_cursor = 0;
+    bool use_fused = true;
+    bool use_gn_small = true;
+    int fused_min = 16, fused_max = 1 << 20;   // resolutions (H) handled by the fused conv path
+    std::unordered_map<int, StatRef> stats_of;   // activation slot -> cached GroupNorm partial sums
     std::vector<float> tp_w, tp_b;      // concatenated time_emb_proj [ntemb][temb_dim], [ntemb]
 
     size_t act_bytes(int C, int H, int W) const { return (size_t)h->cfg.max_batch * H * W * C * 2; }
@@ -279,27 +296,130 @@ struct Builder {
         h->ops.push_back(Op{cls, flops, std::move(fn), cur_name});
     }
 
-    // GroupNorm(32) of cat(x1, x2) followed by optional SiLU -> out
-    void group_norm(const Act &x1, const Act *x2, const std::string &pname, bool silu, const Act &out) {
+    // per-(sample, channel) partial sums of x: produced by the fused conv epilogue when possible,
+    // otherwise by one gn_stats launch right here (once per tensor, reused by every consumer)
+    StatRef ensure_stats(const Act &x) {
+        auto it = stats_of.find(x.slot);
+        if (it != stats_of.end()) return it->second;
         bndm_unet *hh = h;
-        cur_name = S("gn   %-44s C=%-4d %dx%d", pname.c_str(), x1.C + (x2 ? x2->C : 0), x1.H, x1.W);
+        const int HW = x.H * x.W, nslab = gn_num_slabs(HW), C = x.C;
+        StatRef sr{h->new_slot((size_t)h->cfg.max_batch * nslab * C * 2 * 4), nslab};
+        const int sx = x.slot, sp = sr.pslot;
+        cur_name = S("gnst %-44s C=%-4d %dx%d", "", C, x.H, x.W);
+        push(OPC_OTHER, 0, [=](RunCtx &r) {
+            return launch_gn_stats(hh->dtype(), hh->P(sx), C, nullptr, 0, r.B, HW, (float *)hh->P(sp), nslab, r.st);
+        });
+        stats_of[x.slot] = sr;
+        return sr;
+    }
+    StatRef new_stats(const Act &x, int nslab) {
+        StatRef sr{h->new_slot((size_t)h->cfg.max_batch * nslab * x.C * 2 * 4), nslab};
+        stats_of[x.slot] = sr;
+        return sr;
+    }
+
+    // scale/shift table of GroupNorm(32)(cat(x1, x2)) -> scratch slot s_ss
+    void gn_table(const Act &x1, const Act *x2, const std::string &pname) {
+        bndm_unet *hh = h;
         const int C1 = x1.C, C2 = x2 ? x2->C : 0, C = C1 + C2, HW = x1.H * x1.W;
-        const int nslab = gn_num_slabs(HW);
+        const StatRef a1 = ensure_stats(x1);
+        const StatRef a2 = x2 ? ensure_stats(*x2) : StatRef{};
         const float *gamma, *beta;
         if ((rc = upload_f32(h, h->hp(pname + ".weight"), &gamma))) return;
         if ((rc = upload_f32(h, h->hp(pname + ".bias"), &beta))) return;
-        h->grow(h->s_part, (size_t)h->cfg.max_batch * nslab * C * 2 * 4);
         h->grow(h->s_ss, (size_t)h->cfg.max_batch * 2 * C * 4);
-        const int s1 = x1.slot, s2 = x2 ? x2->slot : -1, so = out.slot;
+        cur_name = S("gnfn %-44s C=%-4d %dx%d", pname.c_str(), C, x1.H, x1.W);
         push(OPC_OTHER, 0, [=](RunCtx &r) {
-            int e = launch_gn_stats(hh->dtype(), hh->P(s1), C1, s2 >= 0 ? hh->P(s2) : nullptr, C2, r.B, HW,
-                                    (float *)hh->P(hh->s_part), nslab, r.st);
-            if (e) return e;
-            e = launch_gn_finalize((const float *)hh->P(hh->s_part), nslab, r.B, HW, C, GROUPS, GN_EPS, gamma, beta,
-                                   (float *)hh->P(hh->s_ss), r.st);
-            if (e) return e;
+            return launch_gn_finalize2((const float *)hh->P(a1.pslot), a1.nslab, C1,
+                                       a2.pslot >= 0 ? (const float *)hh->P(a2.pslot) : nullptr, a2.nslab, C2, r.B, HW,
+                                       GROUPS, GN_EPS, gamma, beta, (float *)hh->P(hh->s_ss), r.st);
+        });
+    }
+
+    // GroupNorm(32) of cat(x1, x2) followed by optional SiLU, materialised -> out (unfused path)
+    void group_norm(const Act &x1, const Act *x2, const std::string &pname, bool silu, const Act &out) {
+        bndm_unet *hh = h;
+        const int C1 = x1.C, C2 = x2 ? x2->C : 0, HW = x1.H * x1.W;
+        if (HW <= 64 && use_gn_small) {
+            // whole sample fits in L2 many times over: statistics + apply in one launch
+            const float *gamma, *beta;
+            if ((rc = upload_f32(h, h->hp(pname + ".weight"), &gamma))) return;
+            if ((rc = upload_f32(h, h->hp(pname + ".bias"), &beta))) return;
+            const int s1 = x1.slot, s2 = x2 ? x2->slot : -1, so = out.slot;
+            cur_name = S("gnsm %-44s C=%-4d %dx%d", pname.c_str(), C1 + C2, x1.H, x1.W);
+            push(OPC_OTHER, 0, [=](RunCtx &r) {
+                return launch_gn_small(hh->dtype(), hh->P(s1), C1, s2 >= 0 ? hh->P(s2) : nullptr, C2, r.B, HW, GROUPS,
+                                       GN_EPS, gamma, beta, silu ? 1 : 0, hh->P(so), r.st);
+            });
+            return;
+        }
+        gn_table(x1, x2, pname);
+        if (rc) return;
+        const int s1 = x1.slot, s2 = x2 ? x2->slot : -1, so = out.slot;
+        cur_name = S("gnap %-44s C=%-4d %dx%d", pname.c_str(), C1 + C2, x1.H, x1.W);
+        push(OPC_OTHER, 0, [=](RunCtx &r) {
             return launch_gn_apply(hh->dtype(), hh->P(s1), C1, s2 >= 0 ? hh->P(s2) : nullptr, C2,
                                    (const float *)hh->P(hh->s_ss), r.B, HW, silu ? 1 : 0, hh->P(so), r.st);
+        });
+    }
+
+    // fused 3x3 conv launch (csrc/unet_fused.hip)
+    struct FIn {
+        Act a;
+        int taps, up, ss_off;
+    };
+    bool can_fuse(int H, int W, int Cout) const {
+        return use_fused && H >= 16 && W >= 16 && H >= fused_min && H <= fused_max && Cout % 128 == 0;
+    }
+    void conv_fused(const std::vector<FIn> &ins, bool normed, int ssC, bool silu, const void *Wp, int Ktot,
+                    const float *bias, int temb_off, const Act *resid, const Act &out, bool want_stats,
+                    const std::string &label) {
+        bndm_unet *hh = h;
+        FusedArgs a{};
+        a.nseg = (int)ins.size();
+        std::vector<int> slots;
+        double mac = 0;
+        for (int i = 0; i < a.nseg; ++i) {
+            a.seg[i].C = ins[i].a.C;
+            a.seg[i].taps = ins[i].taps;
+            a.seg[i].up = ins[i].up;
+            a.seg[i].ss_off = ins[i].ss_off;
+            slots.push_back(ins[i].a.slot);
+            mac += (double)ins[i].taps * ins[i].a.C;
+        }
+        a.ssC = ssC;
+        a.silu = silu ? 1 : 0;
+        a.Wgt = Wp;
+        a.Ktot = Ktot;
+        a.bias = bias;
+        a.temb_off = temb_off >= 0 ? temb_off : 0;
+        a.H = out.H;
+        a.W = out.W;
+        a.Cout = out.C;
+        a.zeros = h->zeros;
+        const int TH = out.H >= 32 ? 16 : 8;
+        {
+            const std::vector<int> tab = build_fused_steps(a.seg, a.nseg, TH);
+            void *dtab;
+            if ((rc = upload(h, tab.data(), tab.size() * sizeof(int), &dtab))) return;
+            a.steps = dtab;
+        }
+        const int rs = resid ? resid->slot : -1, so = out.slot;
+        int pst = -1;
+        if (want_stats) pst = new_stats(out, conv_fused_tiles_per_sample(TH, out.H, out.W)).pslot;
+        else stats_of.erase(out.slot);
+        cur_name = S("cnvF %-44s K=%-5d N=%-4d %dx%d", label.c_str(), Ktot, out.C, out.H, out.W);
+        push(OPC_CONV, 2.0 * mac * out.C * out.H * out.W, [=](RunCtx &r) {
+            FusedArgs c = a;
+            for (int i = 0; i < c.nseg; ++i) c.seg[i].src = hh->P(slots[i]);
+            c.B = r.B;
+            c.ss = normed ? (const float *)hh->P(hh->s_ss) : nullptr;
+            c.temb = temb_off >= 0 ? (r.tp_row ? r.tp_row : (const float *)hh->P(hh->s_tp)) : nullptr;
+            c.temb_bstride = r.tp_row ? 0 : hh->ntemb;
+            c.resid = rs >= 0 ? hh->P(rs) : nullptr;
+            c.out = hh->P(so);
+            c.stats = pst >= 0 ? (float *)hh->P(pst) : nullptr;
+            return launch_conv_fused(hh->dtype(), TH, c, r.st);
         });
     }
 
@@ -334,13 +454,14 @@ struct Builder {
         a.Ktot = Ktot;
         a.zeros = h->zeros;
         const int rs = resid ? resid->slot : -1, so = out.slot;
+        stats_of.erase(out.slot);
         const int ksteps = Ktot / 64;
         const double flops = 2.0 * mac * out.C * out.H * out.W;
         // split-K workspace is sized at launch-independent worst case (max_batch)
         {
             const int M = h->cfg.max_batch * out.H * out.W;
             const int nblk = ceil_div(M, 128) * ceil_div(out.C, 128);
-            if (nblk < 128) h->grow(h->s_splitk, (size_t)32 * M * out.C * 4);
+            if (nblk < 192) h->grow(h->s_splitk, (size_t)32 * M * out.C * 4);
         }
         push(OPC_CONV, flops, [=](RunCtx &r) mutable {
             ConvArgs c = a;
@@ -348,29 +469,38 @@ struct Builder {
             c.B = r.B;
             c.resid = rs >= 0 ? hh->P(rs) : nullptr;
             if (temb_off >= 0) {
-                c.temb = (const float *)hh->P(hh->s_tp);
-                c.temb_bstride = hh->ntemb;
+                c.temb = r.tp_row ? r.tp_row : (const float *)hh->P(hh->s_tp);
+                c.temb_bstride = r.tp_row ? 0 : hh->ntemb;
             } else {
                 c.temb = nullptr;
                 c.temb_off = 0;
             }
             const int M = r.B * c.H * c.W;
-            const int nblk = ceil_div(M, 128) * ceil_div(c.Cout, 128);
+            int tile = TILE_256x128;
+            int nblk = ceil_div(M, 256) * ceil_div(c.Cout, 128);
+            if (nblk < 192) {
+                tile = TILE_128x128;
+                nblk = ceil_div(M, 128) * ceil_div(c.Cout, 128);
+            }
             int splitk = 1;
-            if (nblk < 128 && ksteps >= 8) {
-                splitk = std::min(std::min(ceil_div(256, nblk), ksteps / 4), 32);
+            if (nblk < 192 && ksteps >= 8) {
+                splitk = std::min(std::min(ceil_div(512, nblk), ksteps / 4), 32);
+                if (splitk >= 2) {
+                    const int per = ceil_div(ksteps, splitk);
+                    splitk = ceil_div(ksteps, per);          // no empty slices
+                }
                 if (splitk < 2) splitk = 1;
             }
             if ((size_t)splitk * M * c.Cout * 4 > hh->bufs[hh->s_splitk].bytes) splitk = 1;
             if (splitk == 1) {
                 c.splitk = 1;
                 c.out = hh->P(so);
-                return launch_conv(hh->dtype(), TILE_128x128, EPI_NHWC16, c, r.st);
+                return launch_conv(hh->dtype(), tile, EPI_NHWC16, c, r.st);
             }
             ConvArgs p = c;
             p.splitk = splitk;
             p.out = hh->P(hh->s_splitk);
-            int e = launch_conv(hh->dtype(), TILE_128x128, EPI_F32_ROWS, p, r.st);
+            int e = launch_conv(hh->dtype(), tile, EPI_F32_ROWS, p, r.st);
             if (e) return e;
             c.out = hh->P(so);
             return launch_splitk_reduce(hh->dtype(), (const float *)hh->P(hh->s_splitk), splitk, c, r.st);
@@ -399,6 +529,50 @@ struct Builder {
             tp_w.insert(tp_w.end(), w.begin(), w.end());
             tp_b.insert(tp_b.end(), b.begin(), b.end());
             temb_cursor += Cout;
+        }
+        if (can_fuse(H, W, Cout)) {
+            // conv1: GN(norm1)+SiLU applied to cat(x1, x2) inside the conv prologue
+            gn_table(x1, x2, name + ".norm1");
+            if (rc) return x1;
+            const void *W1;
+            int K1;
+            std::vector<WSeg> w1{WSeg{&h->hp(name + ".conv1.weight"), Cin, 0, C1, 9}};
+            std::vector<FIn> in1{FIn{x1, 9, 0, 0}};
+            if (x2) {
+                w1.push_back(WSeg{&h->hp(name + ".conv1.weight"), Cin, C1, C2, 9});
+                in1.push_back(FIn{*x2, 9, 0, C1});
+            }
+            if ((rc = pack_conv_weight(h, w1, Cout, 128, &W1, &K1))) return x1;
+            Act h1 = scratch(h->s_h1, Cout, H, W);
+            conv_fused(in1, true, Cin, true, W1, K1, bias_of(name + ".conv1"), temb_off, nullptr, h1, true,
+                       name + ".conv1");
+            if (rc) return x1;
+            // conv2 (+ 1x1 conv_shortcut on the raw inputs, or identity residual)
+            gn_table(h1, nullptr, name + ".norm2");
+            if (rc) return x1;
+            Act out = new_act(Cout, H, W);
+            const void *W2;
+            int K2;
+            std::vector<WSeg> w2{WSeg{&h->hp(name + ".conv2.weight"), Cout, 0, Cout, 9}};
+            std::vector<FIn> in2{FIn{h1, 9, 0, 0}};
+            const float *b2;
+            if (Cin != Cout) {
+                const std::string sc = name + ".conv_shortcut";
+                w2.push_back(WSeg{&h->hp(sc + ".weight"), Cin, 0, C1, 1});
+                in2.push_back(FIn{x1, 1, 0, -1});
+                if (x2) {
+                    w2.push_back(WSeg{&h->hp(sc + ".weight"), Cin, C1, C2, 1});
+                    in2.push_back(FIn{*x2, 1, 0, -1});
+                }
+                b2 = bias_of(name + ".conv2", &sc);
+            } else {
+                b2 = bias_of(name + ".conv2");
+            }
+            if (rc) return x1;
+            if ((rc = pack_conv_weight(h, w2, Cout, 128, &W2, &K2))) return x1;
+            conv_fused(in2, true, Cout, true, W2, K2, b2, -1, Cin == Cout ? &x1 : nullptr, out, true,
+                       name + (Cin != Cout ? ".conv2+sc" : ".conv2"));
+            return out;
         }
         Act y1 = scratch(h->s_y, Cin, H, W);
         group_norm(x1, x2, name + ".norm1", true, y1);
@@ -478,6 +652,10 @@ struct Builder {
         rc = pack_conv_weight(h, {WSeg{&h->hp(name + ".weight"), x.C, 0, x.C, 9}}, x.C, 128, &Wp, &K);
         if (rc) return x;
         Act out = down ? new_act(x.C, x.H / 2, x.W / 2) : new_act(x.C, x.H * 2, x.W * 2);
+        if (!down && can_fuse(out.H, out.W, out.C)) {
+            conv_fused({FIn{x, 9, 1, -1}}, false, 0, false, Wp, K, bias_of(name), -1, nullptr, out, true, name);
+            return out;
+        }
         conv({SegIn{x, 9, down ? 0 : 1}}, Wp, K, bias_of(name), -1, nullptr, out, down ? 2 : 1, name);
         return out;
     }
@@ -525,9 +703,13 @@ struct Builder {
             if ((rc = upload_f32(h, h->hp("time_embedding.linear_2.bias"), &db2))) return rc;
             cur_name = "temb_mlp";
             push(OPC_OTHER, 0, [=](RunCtx &r) {
+                if (r.tp_row) return 0;
                 return launch_temb_mlp(hh->dtype(), r.timesteps, r.B, C0, D, dw1, db1, dw2, db2, hh->P(hh->s_actemb),
                                        r.st);
             });
+            hh->temb_table_fn = [=](int n, const float *t_dev, void *act, float *table, hipStream_t st) {
+                return launch_temb_mlp(hh->dtype(), t_dev, n, C0, D, dw1, db1, dw2, db2, act, st);
+            };
         }
         const size_t temb_proj_op = h->ops.size();
         cur_name = "conv time_emb_proj (all resnets)";
@@ -550,11 +732,12 @@ struct Builder {
             const float *db = bias_of("conv_in");
             if (rc) return rc;
             const int so = x.slot;
+            const int sst = new_stats(x, R * R / 128).pslot;
             cur_name = "conv_in";
             push(OPC_OTHER, 0, [=](RunCtx &r) {
                 const int Ce = r.extra ? Cin / 2 : 0;     // conditional sampler: x and x_c have equal channels
-                return launch_conv_in(hh->dtype(), r.sample, Cin - Ce, r.extra, Ce, dW, db, hh->P(so), r.B, R, R, C0,
-                                      KP, r.st);
+                return launch_conv_in(hh->dtype(), r.sample, Cin - Ce, r.extra, Ce, dW, db, hh->P(so),
+                                      (float *)hh->P(sst), r.B, R, R, C0, KP, r.st);
             });
         }
 
@@ -657,7 +840,18 @@ struct Builder {
             a.Ktot = K;
             a.splitk = 1;
             a.zeros = h->zeros;
+            auto mlp_fn = h->temb_table_fn;
+            h->temb_table_fn = [=](int n, const float *t_dev, void *act, float *table, hipStream_t st) {
+                int e = mlp_fn(n, t_dev, act, table, st);
+                if (e) return e;
+                ConvArgs cc = a;
+                cc.seg[0].src = act;
+                cc.B = n;
+                cc.out = table;
+                return launch_conv(hh->dtype(), TILE_128x128, EPI_F32_ROWS, cc, st);
+            };
             h->ops[temb_proj_op] = Op{OPC_CONV, 2.0 * D * h->ntemb, [=](RunCtx &r) {
+                                          if (r.tp_row) return 0;
                                           ConvArgs cc = a;
                                           cc.seg[0].src = hh->P(hh->s_actemb);
                                           cc.B = r.B;
@@ -677,6 +871,23 @@ int run_forward(bndm_unet *h, RunCtx &r) {
         if (r.prof) BNDM_CHECK_HIP(hipEventRecord((*r.ev)[2 * i + 1], r.st));
     }
     return 0;
+}
+
+// time-embedding projections of every step of a schedule, computed once per sampling call (K10)
+int prepare_temb_table(bndm_unet *h, int n, const float *t_host, hipStream_t st) {
+    if (n > h->tp_cap) {
+        BNDM_CHECK_HIP(hipStreamSynchronize(st));
+        if (h->tp_table) (void)hipFree(h->tp_table);
+        if (h->t_steps) (void)hipFree(h->t_steps);
+        if (h->act_steps) (void)hipFree(h->act_steps);
+        h->tp_table = nullptr; h->t_steps = nullptr; h->act_steps = nullptr; h->tp_cap = 0;
+        BNDM_CHECK_HIP(hipMalloc((void **)&h->tp_table, (size_t)n * h->ntemb * 4));
+        BNDM_CHECK_HIP(hipMalloc((void **)&h->t_steps, (size_t)n * 4));
+        BNDM_CHECK_HIP(hipMalloc(&h->act_steps, (size_t)n * h->temb_dim * 2));
+        h->tp_cap = n;
+    }
+    BNDM_CHECK_HIP(hipMemcpyAsync(h->t_steps, t_host, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    return h->temb_table_fn(n, h->t_steps, h->act_steps, h->tp_table, st);
 }
 
 __global__ void fill_f32_kernel(float *p, float v, int n) {
@@ -711,8 +922,8 @@ extern "C" int bndm_unet_create(bndm_unet **out, const bndm_unet_config *cfg) {
                  cfg->num_levels);
     BNDM_REQUIRE(cfg->dtype == BNDM_DTYPE_F16 || cfg->dtype == BNDM_DTYPE_BF16, "bndm_unet_create: dtype %d",
                  cfg->dtype);
-    BNDM_REQUIRE(cfg->resolution >= 8 && (cfg->resolution & (cfg->resolution - 1)) == 0,
-                 "bndm_unet_create: resolution %d must be a power of two >= 8", cfg->resolution);
+    BNDM_REQUIRE(cfg->resolution >= 16 && (cfg->resolution & (cfg->resolution - 1)) == 0,
+                 "bndm_unet_create: resolution %d must be a power of two >= 16", cfg->resolution);
     BNDM_REQUIRE((cfg->resolution >> (cfg->num_levels - 1)) >= 1, "bndm_unet_create: too many levels for resolution");
     BNDM_REQUIRE(cfg->in_channels >= 1 && cfg->in_channels * 9 <= 64 && cfg->out_channels >= 1 &&
                      cfg->out_channels <= 32,
@@ -742,6 +953,9 @@ extern "C" int bndm_unet_create(bndm_unet **out, const bndm_unet_config *cfg) {
 extern "C" void bndm_unet_destroy(bndm_unet *h) {
     if (!h) return;
     for (void *p : h->weights) (void)hipFree(p);
+    if (h->tp_table) (void)hipFree(h->tp_table);
+    if (h->t_steps) (void)hipFree(h->t_steps);
+    if (h->act_steps) (void)hipFree(h->act_steps);
     for (Buf &b : h->bufs)
         if (b.ptr) (void)hipFree(b.ptr);
     delete h;
@@ -781,6 +995,10 @@ extern "C" int bndm_unet_finalize(bndm_unet *h) {
             return BNDM_E_STATE;
         }
     Builder b{h};
+    if (const char *e = getenv("BNDM_NO_FUSED")) b.use_fused = !(e[0] == '1');
+    if (const char *e = getenv("BNDM_NO_GN_SMALL")) b.use_gn_small = !(e[0] == '1');
+    if (const char *e = getenv("BNDM_FUSED_MIN")) b.fused_min = atoi(e);
+    if (const char *e = getenv("BNDM_FUSED_MAX")) b.fused_max = atoi(e);
     int rc = b.build();
     if (rc) return rc;
     for (Buf &bf : h->bufs) {
@@ -815,9 +1033,10 @@ extern "C" int bndm_unet_sample_iadb(bndm_unet *h, float *x, const float *extra_
     float *tbuf = (float *)h->P(h->s_t), *dbuf = (float *)h->P(h->s_d);
     const size_t img = (size_t)B * C * R * R;
     int snap = 0;
+    if (nb_step > 0 && (rc = prepare_temb_table(h, nb_step, t_in, st))) return rc;
     for (int s = 0; s < nb_step; ++s) {
-        hipLaunchKernelGGL(fill_f32_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, st, tbuf, t_in[s], B);
         RunCtx r{B, st, x, extra_in, tbuf, dbuf};
+        r.tp_row = h->tp_table + (size_t)s * h->ntemb;
         if ((rc = run_forward(h, r))) return rc;
         if ((rc = bndm_iadb_step(x, dbuf, da[s], dg[s], B, C, Cout, R * R, stream))) return rc;
         if (snap_mask && snapshots && snap_mask[s]) {
@@ -838,10 +1057,16 @@ extern "C" int bndm_unet_sample_ddim(bndm_unet *h, float *x, int B, int nb_step,
     const int R = h->cfg.resolution;
     float *tbuf = (float *)h->P(h->s_t), *dbuf = (float *)h->P(h->s_d);
     const size_t n = (size_t)B * h->cfg.in_channels * R * R;
+    if (nb_step > 0) {
+        std::vector<float> ts(nb_step);
+        for (int s = 0; s < nb_step; ++s) ts[s] = coef[5 * s];
+        if ((rc = prepare_temb_table(h, nb_step, ts.data(), st))) return rc;
+        BNDM_CHECK_HIP(hipStreamSynchronize(st));      // ts is a stack-lifetime host buffer
+    }
     for (int s = 0; s < nb_step; ++s) {
         const float *c = coef + 5 * s;
-        hipLaunchKernelGGL(fill_f32_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, st, tbuf, c[0], B);
         RunCtx r{B, st, x, nullptr, tbuf, dbuf};
+        r.tp_row = h->tp_table + (size_t)s * h->ntemb;
         if ((rc = run_forward(h, r))) return rc;
         if ((rc = bndm_ddim_step(x, dbuf, c[1], c[2], c[3], c[4], clip, n, stream))) return rc;
     }

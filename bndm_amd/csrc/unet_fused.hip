@@ -1,0 +1,634 @@
+// Fused stride-1 3x3 convolution for the FLOP-dominant UNet layers (ResnetBlock2D conv1 / conv2 +
+// conv_shortcut, Upsample2D conv) -- see the interface comment in unet_kernels.hpp.
+//
+// Block = 512 threads (8 waves as 4(M) x 2(N)) computing a TH x 16 pixel tile of one sample x 128
+// output channels.  K runs over 64-channel chunks of up to 4 segments; for every chunk the
+// (TH+2) x 18 input halo patch is loaded ONCE into registers, GroupNorm scale/shift (+SiLU) is
+// applied there, and the result is written to an XOR-swizzled LDS patch (double-buffered).  The 9 taps
+// of the chunk then read their MFMA fragments from that patch at shifted pixel offsets, so activation
+// traffic and the normalisation arithmetic are paid 1.27x instead of 9x.  Weight tiles ([128][64] per
+// tap) stream through a 3-deep global_load_lds ring with counted vmcnt waits and one raw s_barrier per
+// K-step.  The epilogue stages the tile through LDS: full 256-B rows are stored, and per-(sample,
+// channel) sums / sums of squares of the stored 16-bit values are reduced deterministically for the
+// GroupNorm that consumes this tensor next.
+#include "unet_kernels.hpp"
+#include "unet_types.hpp"
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+namespace bndm {
+namespace {
+
+// One int4 per K-step, built on the host (build_fused_steps) so the device loop carries no iterator
+// state, no segment-table loads and almost no scalar bookkeeping:
+//   x  weight k-offset (elements) of step s+2 (clamped)        -> weight DMA issued in the even phase of s
+//   y  read descriptor of step s: tap offset (ky*18+kx) | patch buffer << 16
+//   z  patch DMA: bit31 issue after the weight DMA (chunk with 8 steps of slack), bit30 issue before it
+//      (raw 1x1 chunk needed next step) | segment << 24 | buffer << 23 | chunk
+//   w  in-place normalisation: bit31 valid | bit30 first round (drain DMA) | segment << 24 | buffer << 23 |
+//      round << 16 | chunk
+struct StepDesc {
+    int x, y, z, w;
+};
+
+// ABL: ablation switches for profiling only (results are wrong when non-zero):
+//   1 skip the MFMAs, 2 skip in-loop weight DMA, 4 skip in-loop LDS fragment reads, 8 skip in-loop patch work
+template <typename T, int TH, int ABL>
+__global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepDesc *__restrict__ steps,
+                                                  const int tiles_x, const int tps, const int ntn,
+                                                  const int nsteps) {
+    using v8 = typename TT<T>::v8;
+    using v4 = typename TT<T>::v4;
+    constexpr int TW = 16, PW = TW + 2, PH = TH + 2;
+    constexpr int NPP = PH * PW;                       // patch pixels
+    constexpr int NPIECE = NPP * 8;                    // 16-byte pieces per patch chunk
+    constexpr int NROUND = (NPIECE + 511) / 512;       // patch DMAs per thread per chunk
+    constexpr int PATCH_BYTES = NROUND * 8192;         // rounded up: tail lanes of the last round land in dead space
+    constexpr int BM = TH * TW;
+    constexpr int TM = TH / 8;                         // 32-pixel MFMA tiles per wave along M
+    constexpr int TN = 2;
+    constexpr int WSTAGES = 3;
+    constexpr int W_BYTES = 128 * 128;
+    constexpr int OFF_W = 2 * PATCH_BYTES;
+    constexpr int OFF_SS = OFF_W + WSTAGES * W_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63;
+
+    // ---- tile id (XCD-aware: neighbouring tiles of a sample share halos and weights) ---------------
+    const int nblk = gridDim.x;
+    int tix;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        tix = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mt = tix / ntn, nt = tix - mt * ntn;
+    const int b = mt / tps, tin = mt - b * tps;
+    const int ty = tin / tiles_x, tx = tin - ty * tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW, n0 = nt * 128;
+    const int H = a.H, Wd = a.W;
+
+    // ---- scale/shift table of this sample -> LDS ([0..ssC) scale, [ssC..2ssC) shift) ---------------
+    float *ssL = reinterpret_cast<float *>(smem + OFF_SS);
+    if (a.ss) {
+        const float *g = a.ss + (size_t)b * 2 * a.ssC;
+        for (int i = tid; i < 2 * a.ssC; i += 512) ssL[i] = g[i];
+    }
+
+    // ---- patch piece descriptors (independent of the chunk) ----------------------------------------
+    int p_lds[NROUND], p_full[NROUND], p_half[NROUND], p_lc[NROUND];
+#pragma unroll
+    for (int r = 0; r < NROUND; ++r) {
+        const int piece = r * 512 + tid;
+        const int pc = piece < NPIECE ? piece : NPIECE - 1;
+        const int pp = pc >> 3, pch = pc & 7;
+        const int pyy = pp / PW, pxx = pp - pyy * PW;
+        const int iy = y0 - 1 + pyy, ix = x0 - 1 + pxx;
+        const bool ok = piece < NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)Wd;
+        p_lds[r] = piece < NPIECE ? pp * 128 + pch * 16 : -1;
+        p_lc[r] = pch ^ ((pp >> 1) & 7);
+        p_full[r] = ok ? (b * H + iy) * Wd + ix : -1;
+        p_half[r] = ok ? (b * (H >> 1) + (iy >> 1)) * (Wd >> 1) + (ix >> 1) : -1;
+    }
+    // The patch of a chunk goes by LDS-DMA straight into its LDS buffer (piece index == LDS order, the
+    // XOR swizzle sits on the source side).  Every thread issues exactly NROUND DMAs per chunk (tail
+    // lanes re-read the zero page into a dead slot past the patch), so vmcnt bookkeeping is identical
+    // in all waves and -- with no ordinary loads left in the loop -- stays a pure LDS-DMA count.
+    // segment parameters by index without dynamic indexing of the kernel argument (that would be a
+    // scalar memory load + lgkmcnt(0) in the middle of the loop)
+    auto seg_of = [&](int si) {
+        FusedSeg sg = a.seg[0];
+        if (si == 1) sg = a.seg[1];
+        if (si == 2) sg = a.seg[2];
+        if (si == 3) sg = a.seg[3];
+        return sg;
+    };
+    auto patch_dma = [&](int sidx, int chunk, int buf) {
+        const FusedSeg sg = seg_of(sidx);
+        const char *sbase = (const char *)sg.src;
+        char *P = smem + buf * PATCH_BYTES;
+#pragma unroll
+        for (int r = 0; r < NROUND; ++r) {
+            const int pix = sg.up ? p_half[r] : p_full[r];
+            const char *src = pix >= 0 ? sbase + ((size_t)pix * sg.C + chunk * 64 + p_lc[r] * 8) * 2
+                                       : (const char *)a.zeros;
+            glds16(src, P + r * 8192 + w * 1024);
+        }
+    };
+    // GroupNorm scale/shift + SiLU applied in place to this thread's own piece of round `round`
+    // (padding pieces stay zero: the reference pads AFTER the activation)
+    auto patch_xform = [&](int sidx, int chunk, int buf, int round) {
+        const FusedSeg sg = seg_of(sidx);
+        char *P = smem + buf * PATCH_BYTES;
+#pragma unroll
+        for (int r = 0; r < NROUND; ++r) {
+            if (r != round) continue;
+            const int pix = sg.up ? p_half[r] : p_full[r];
+            if (p_lds[r] < 0 || pix < 0) continue;
+            const v8 v = *reinterpret_cast<const v8 *>(P + p_lds[r]);
+            const float *sc = ssL + sg.ss_off + chunk * 64 + p_lc[r] * 8;
+            const float *sh = sc + a.ssC;
+            const f32x4 s0 = *reinterpret_cast<const f32x4 *>(sc), s1 = *reinterpret_cast<const f32x4 *>(sc + 4);
+            const f32x4 h0 = *reinterpret_cast<const f32x4 *>(sh), h1 = *reinterpret_cast<const f32x4 *>(sh + 4);
+            v8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = fmaf((float)v[e], e < 4 ? s0[e & 3] : s1[e & 3], e < 4 ? h0[e & 3] : h1[e & 3]);
+                // SiLU with hardware exp2 / rcp (every normalised segment of this kernel is followed by SiLU)
+                o[e] = (T)(f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f)));
+            }
+            *reinterpret_cast<v8 *>(P + p_lds[r]) = o;
+        }
+    };
+
+    // ---- weight tile staging: 128 rows x 128 B = 1024 pieces, 2 per thread ---------------------------
+    const int wrow = tid >> 3;
+    const int wlchunk = (tid & 7) ^ ((tid >> 4) & 7);
+    const char *wsrc0 = (const char *)a.Wgt + ((size_t)(n0 + wrow) * a.Ktot + wlchunk * 8) * 2;
+    const char *wsrc1 = wsrc0 + (size_t)64 * a.Ktot * 2;
+    auto w_issue = [&](int buf, int kofs) {
+        char *base = smem + OFF_W + buf * W_BYTES;
+        glds16(wsrc0 + (size_t)kofs * 2, base + w * 1024);
+        glds16(wsrc1 + (size_t)kofs * 2, base + 8192 + w * 1024);
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int wm = w & 3, wn = w >> 2;
+    const int q = l & 31, kh = l >> 5, wkey = (l >> 1) & 7;
+    const int row_base = wm * (TH / 4);
+    const int lr = q >> 4, lcx = q & 15;
+
+    // ---- ping-pong schedule ------------------------------------------------------------------------
+    // Waves 0-3 (group A) and 4-7 (group B) share the four SIMDs pairwise.  Every K-step has two phases,
+    // each opened by a barrier:   even: A multiplies step s from registers | B reads step s from LDS
+    //                             odd : A reads step s+1 from LDS          | B multiplies step s
+    // so on every SIMD one wave feeds the matrix pipe while its partner does LDS / DMA work.
+    // Weight tile s+2 is issued in the even phase of step s (3-deep ring; a counted vmcnt before the odd
+    // barrier certifies tile s+1).  The patch of the next chunk is DMA'd at tap 0 of the current one and
+    // normalised in place one round per step (taps 1..NROUND), all by the thread that issued the piece.
+    // Everything that varies per step comes from the host-built StepDesc table (one s_load per step).
+    v8 fa[4][TN], fb[4][TM];
+    // per-lane address constants
+    const int wconst = (wn * 64 + q) * 128 + ((kh ^ wkey) << 4);       // ks folded in by xor (ks << 5)
+    int pr0[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) pr0[j] = (row_base + 2 * j + lr) * PW + lcx;
+    const int c0x = kh << 4;
+    auto read_frags = [&](int rd, int wbuf) {
+        const int tapoff = rd & 0xffff, pb = rd >> 16;
+        const char *P = smem + pb * PATCH_BYTES;
+        const char *Wt = smem + OFF_W + wbuf * W_BYTES;
+        int xb[TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int pr = pr0[j] + tapoff;
+            xb[j] = ((pr << 7) | (((pr >> 1) & 7) << 4)) ^ c0x;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                fa[ks][i] = *reinterpret_cast<const v8 *>(Wt + ((wconst ^ (ks << 5)) + i * 4096));
+#pragma unroll
+            for (int j = 0; j < TM; ++j) fb[ks][j] = *reinterpret_cast<const v8 *>(P + (xb[j] ^ (ks << 5)));
+        }
+    };
+    auto multiply = [&]() {
+        if (ABL & 1) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int i = 0; i < TN; ++i) asm volatile("" ::"v"(fa[ks][i]));
+#pragma unroll
+                for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(fb[ks][j]));
+            }
+            return;
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = TT<T>::mfma(fa[ks][i], fb[ks][j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // work common to both groups at the start of the even phase of a step
+    auto even_common = [&](const StepDesc &d, int wnext) -> bool {
+        if (!(ABL & 8) && d.w < 0) {                    // one normalisation round, in place
+            if (d.w & (1 << 30)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // patch DMA is the youngest
+            patch_xform((d.w >> 24) & 3, d.w & 0xffff, (d.w >> 23) & 1, (d.w >> 16) & 7);
+        }
+        if (!(ABL & 8) && (d.z & (1 << 30))) patch_dma((d.z >> 24) & 3, d.z & 0xffff, (d.z >> 23) & 1);
+        asm volatile("" ::: "memory");
+        if (!(ABL & 2)) w_issue(wnext, d.x);
+        asm volatile("" ::: "memory");
+        if (!(ABL & 8) && d.z < 0) {
+            patch_dma((d.z >> 24) & 3, d.z & 0xffff, (d.z >> 23) & 1);
+            asm volatile("" ::: "memory");
+            return true;
+        }
+        return false;
+    };
+
+    const bool grpA = wn == 0;                         // wave-uniform (w is an SGPR)
+    StepDesc dcur = steps[0];
+    StepDesc dnext = steps[nsteps > 1 ? 1 : 0];
+
+    // ---- prologue: chunk 0 and weight tiles 0, 1 in flight together; then normalise chunk 0 ------------
+    patch_dma(0, 0, 0);
+    w_issue(0, steps[nsteps].x);                        // the table carries the k-offsets of steps 0 / 1 at the end
+    w_issue(1, steps[nsteps].y);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // own patch pieces landed (weights may still fly)
+    __syncthreads();                                   // ss table visible (written above by plain stores)
+    if (a.seg[0].ss_off >= 0) {
+#pragma unroll
+        for (int r = 0; r < NROUND; ++r) patch_xform(0, 0, 0, r);
+    }
+    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    int wcur = 0, wnext = 2;
+    if (grpA) {
+        read_frags(dcur.y, 0);
+        for (int s = 0; s < nsteps; ++s) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const bool issued = even_common(dcur, wnext);
+            multiply();
+            if (issued) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 + NROUND) : "memory");
+            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int wn1 = wcur + 1 == WSTAGES ? 0 : wcur + 1;
+            if (!(ABL & 4) && s + 1 < nsteps) read_frags(dnext.y, wn1);
+            dcur = dnext;
+            dnext = steps[s + 2 < nsteps ? s + 2 : nsteps - 1];
+            wcur = wn1;
+            wnext = wnext + 1 == WSTAGES ? 0 : wnext + 1;
+        }
+    } else {
+        for (int s = 0; s < nsteps; ++s) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const bool issued = even_common(dcur, wnext);
+            if (!(ABL & 4)) read_frags(dcur.y, wcur);
+            if (issued) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 + NROUND) : "memory");
+            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            multiply();
+            dcur = dnext;
+            dnext = steps[s + 2 < nsteps ? s + 2 : nsteps - 1];
+            wcur = wcur + 1 == WSTAGES ? 0 : wcur + 1;
+            wnext = wnext + 1 == WSTAGES ? 0 : wnext + 1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                   // all LDS reads and tail DMAs done: reuse LDS
+
+    // ---- epilogue 1: bias + time embedding + residual -> 16-bit tile in LDS ([BM][128 ch], swizzled) --
+    char *stg = smem;
+    const float *tembp = a.temb ? a.temb + (size_t)b * a.temb_bstride + a.temb_off : nullptr;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int prow = row_base + 2 * j + lr;
+        const int pl = prow * TW + lcx;                                   // pixel inside the tile
+        const size_t m = (size_t)(b * H + y0 + prow) * Wd + x0 + lcx;     // global pixel
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = wn * 64 + i * 32 + 8 * g + 4 * kh;         // channel inside the block
+                const int co = n0 + cl;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                if (a.bias) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.bias + co);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                }
+                if (tembp) {
+                    const f32x4 tv = *reinterpret_cast<const f32x4 *>(tembp + co);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += tv[e];
+                }
+                if (a.resid) {
+                    const v4 rv = *reinterpret_cast<const v4 *>((const T *)a.resid + m * a.Cout + co);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                }
+                v4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = (T)v[e];
+                *reinterpret_cast<v4 *>(stg + pl * 256 + ((((cl >> 3) ^ (pl & 15)) << 4) | ((cl & 7) * 2))) = ov;
+            }
+    }
+    __syncthreads();
+
+    // ---- epilogue 2: full-row stores + per-channel statistics of the stored values -------------------
+    const int c16 = tid & 15, prw = tid >> 4;            // 16-byte chunk (8 channels), pixel row slot
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) {
+        const int pl = prw + 32 * i;
+        const v8 v = *reinterpret_cast<const v8 *>(stg + pl * 256 + ((c16 ^ (pl & 15)) << 4));
+        const size_t m = (size_t)(b * H + y0 + (pl >> 4)) * Wd + x0 + (pl & 15);
+        *reinterpret_cast<v8 *>((T *)a.out + m * a.Cout + n0 + c16 * 8) = v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = (float)v[e];
+            s1[e] += f;
+            s2[e] = fmaf(f, f, s2[e]);
+        }
+    }
+    if (a.stats) {
+        float *red = reinterpret_cast<float *>(smem + BM * 256);           // [32][128][2]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[((prw * 128) + c16 * 8 + e) * 2 + 0] = s1[e];
+            red[((prw * 128) + c16 * 8 + e) * 2 + 1] = s2[e];
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const int ch = tid >> 1, which = tid & 1;
+            float t = 0.f;
+            for (int r = 0; r < 32; ++r) t += red[((r * 128) + ch) * 2 + which];
+            a.stats[((size_t)(b * tps + tin) * a.Cout + n0 + ch) * 2 + which] = t;
+        }
+    }
+}
+
+template <typename T, int TH, int ABL>
+int launch_fused_t(const FusedArgs &a, hipStream_t st) {
+    constexpr int PATCH_BYTES = (((TH + 2) * 18 * 8 + 511) / 512) * 8192;
+    constexpr int main_bytes = 2 * PATCH_BYTES + 3 * 16384 + 8192;
+    constexpr int epi_bytes = TH * 16 * 256 + 32 * 128 * 2 * 4;
+    constexpr int smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+    static bool attr = false;
+    if (!attr) {
+        BNDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_fused<T, TH, ABL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr = true;
+    }
+    const int tiles_x = a.W / 16, tiles_y = a.H / TH, tps = tiles_x * tiles_y, ntn = a.Cout / 128;
+    int nsteps = 0;
+    for (int i = 0; i < a.nseg; ++i) nsteps += a.seg[i].taps * (a.seg[i].C / 64);
+    dim3 grid(a.B * tps * ntn);
+    hipLaunchKernelGGL((conv_fused<T, TH, ABL>), grid, dim3(512), smem, st, a, (const StepDesc *)a.steps, tiles_x, tps,
+                       ntn, nsteps);
+    return launch_status("conv_fused");
+}
+
+// cat(x1, x2) statistics from per-tensor partial sums
+__global__ __launch_bounds__(256) void gn_finalize2_kernel(const float *__restrict__ p1, int nslab1, int C1,
+                                                           const float *__restrict__ p2, int nslab2, int C2, int HW,
+                                                           int groups, float eps, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta,
+                                                           float *__restrict__ scale_shift) {
+    __shared__ double cs[1024], css[1024];
+    const int b = blockIdx.x, C = C1 + C2;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float *p;
+        int ns, Cs, cc;
+        if (c < C1) { p = p1; ns = nslab1; Cs = C1; cc = c; } else { p = p2; ns = nslab2; Cs = C2; cc = c - C1; }
+        double s = 0, q = 0;
+        for (int k = 0; k < ns; ++k) {
+            const float *pp = p + ((size_t)(b * ns + k) * Cs + cc) * 2;
+            s += pp[0];
+            q += pp[1];
+        }
+        cs[c] = s;
+        css[c] = q;
+    }
+    __syncthreads();
+    const int Cg = C / groups;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g0 = (c / Cg) * Cg;
+        double s = 0, q = 0;
+        for (int k = 0; k < Cg; ++k) {
+            s += cs[g0 + k];
+            q += css[g0 + k];
+        }
+        const double n = (double)Cg * HW;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        var = var > 0 ? var : 0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = rstd * gamma[c];
+        scale_shift[((size_t)b * 2 + 0) * C + c] = sc;
+        scale_shift[((size_t)b * 2 + 1) * C + c] = beta[c] - (float)mean * sc;
+    }
+}
+
+// GroupNorm(32) (+SiLU) of cat(x1, x2) for one whole sample per block: statistics and application in
+// one launch (the low-resolution layers, where a sample's tensor is at most ~100 KB and stays in L2).
+template <typename T>
+__global__ __launch_bounds__(512) void gn_small_kernel(const T *__restrict__ x1, int C1, const T *__restrict__ x2,
+                                                       int C2, int HW, int groups, float eps,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                       int silu, T *__restrict__ out) {
+    using v8 = typename TT<T>::v8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int C = C1 + C2, CH = C >> 3, RP = 512 / CH;
+    float *red = reinterpret_cast<float *>(smem);                 // [RP][C][2]
+    float *ss = red + (size_t)RP * C * 2;                         // [2][C]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int chunk = tid % CH, prow = tid / CH;
+    const int c0 = chunk * 8;
+    const T *src = c0 < C1 ? x1 + (size_t)b * HW * C1 + c0 : x2 + (size_t)b * HW * C2 + (c0 - C1);
+    const int Cs = c0 < C1 ? C1 : C2;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    if (prow < RP)
+        for (int p = prow; p < HW; p += RP) {
+            const v8 v = *reinterpret_cast<const v8 *>(src + (size_t)p * Cs);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)v[e];
+                s1[e] += f;
+                s2[e] = fmaf(f, f, s2[e]);
+            }
+        }
+    if (prow < RP) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[((size_t)prow * C + c0 + e) * 2 + 0] = s1[e];
+            red[((size_t)prow * C + c0 + e) * 2 + 1] = s2[e];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * C; i += 512) {                       // per-channel totals in row 0
+        float t = red[i];
+        for (int r = 1; r < RP; ++r) t += red[(size_t)r * C * 2 + i];
+        red[i] = t;
+    }
+    __syncthreads();
+    const int Cg = C / groups;
+    for (int c = tid; c < C; c += 512) {
+        const int g0 = (c / Cg) * Cg;
+        double s = 0, q = 0;
+        for (int k = 0; k < Cg; ++k) {
+            s += red[(g0 + k) * 2];
+            q += red[(g0 + k) * 2 + 1];
+        }
+        const double n = (double)Cg * HW, mean = s / n;
+        double var = q / n - mean * mean;
+        var = var > 0 ? var : 0;
+        const float sc = (float)(1.0 / sqrt(var + (double)eps)) * gamma[c];
+        ss[c] = sc;
+        ss[C + c] = beta[c] - (float)mean * sc;
+    }
+    __syncthreads();
+    if (prow < RP)
+        for (int p = prow; p < HW; p += RP) {
+            const v8 v = *reinterpret_cast<const v8 *>(src + (size_t)p * Cs);
+            v8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = fmaf((float)v[e], ss[c0 + e], ss[C + c0 + e]);
+                if (silu) f = f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f));
+                o[e] = (T)f;
+            }
+            *reinterpret_cast<v8 *>(out + ((size_t)b * HW + p) * C + c0) = o;
+        }
+}
+
+}  // namespace
+
+// Host: the per-step schedule of conv_fused for a segment list (see StepDesc).  Returns nsteps + 1
+// entries; the extra last entry carries the weight k-offsets of steps 0 and 1 for the prologue.
+std::vector<int> build_fused_steps(const FusedSeg *seg, int nseg, int TH) {
+    const int PW = 18;
+    const int NROUND = ((TH + 2) * 18 * 8 + 511) / 512;
+    struct St { int seg, chunk, tap, taps, cidx, kofs; };
+    std::vector<St> st;
+    int koff = 0, cidx = 0;
+    for (int i = 0; i < nseg; ++i) {
+        for (int c = 0; c < seg[i].C / 64; ++c, ++cidx)
+            for (int t = 0; t < seg[i].taps; ++t)
+                st.push_back(St{i, c, t, seg[i].taps, cidx, koff + (seg[i].taps == 9 ? t * seg[i].C : 0) + c * 64});
+        koff += seg[i].taps * seg[i].C;
+    }
+    const int n = (int)st.size(), nchunks = cidx;
+    std::vector<int> out((size_t)(n + 1) * 4, 0);
+    std::vector<int> first(nchunks + 1, n);             // first step of every chunk
+    for (int s = n - 1; s >= 0; --s) first[st[s].cidx] = s;
+    for (int s = 0; s < n; ++s) {
+        const St &c = st[s];
+        int *d = &out[(size_t)s * 4];
+        d[0] = st[std::min(s + 2, n - 1)].kofs;
+        const int ky = c.taps == 9 ? c.tap / 3 : 1, kx = c.taps == 9 ? c.tap % 3 : 1;
+        d[1] = (ky * PW + kx) | ((c.cidx & 1) << 16);
+        // chunk DMA'd at tap 0 of its 9-tap predecessor
+        if (c.taps == 9 && c.tap == 0 && c.cidx + 1 < nchunks) {
+            const St &nx = st[first[c.cidx + 1]];
+            d[2] = (int)(0x80000000u | (nx.seg << 24) | ((nx.cidx & 1) << 23) | nx.chunk);
+        }
+        // raw 1x1 chunk that follows a 1x1 chunk: issued one step ahead, before the weight DMA
+        if (c.taps == 1 && s + 1 < n && st[s + 1].cidx != c.cidx) {
+            const St &nx = st[s + 1];
+            d[2] |= (1 << 30) | (nx.seg << 24) | ((nx.cidx & 1) << 23) | nx.chunk;
+        }
+        // in-place normalisation rounds of the next chunk at taps 1..NROUND of a 9-tap chunk
+        if (c.taps == 9 && c.tap >= 1 && c.tap <= NROUND && c.cidx + 1 < nchunks) {
+            const St &nx = st[first[c.cidx + 1]];
+            if (seg[nx.seg].ss_off >= 0)
+                d[3] = (int)(0x80000000u | (c.tap == 1 ? (1 << 30) : 0) | (nx.seg << 24) | ((nx.cidx & 1) << 23) |
+                             ((c.tap - 1) << 16) | nx.chunk);
+        }
+    }
+    out[(size_t)n * 4 + 0] = st[0].kofs;
+    out[(size_t)n * 4 + 1] = st[std::min(1, n - 1)].kofs;
+    return out;
+}
+
+int conv_fused_tiles_per_sample(int TH, int H, int W) { return (H / TH) * (W / 16); }
+
+int launch_conv_fused(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
+    if ((TH != 8 && TH != 16) || a.H % TH || a.W % 16 || a.Cout % 128 || a.nseg < 1 || a.nseg > CONV_MAX_SEG) {
+        set_error("launch_conv_fused: unsupported shape TH=%d H=%d W=%d Cout=%d nseg=%d", TH, a.H, a.W, a.Cout,
+                  a.nseg);
+        return BNDM_E_ARG;
+    }
+    for (int i = 0; i < a.nseg; ++i)
+        if (a.seg[i].C % 64 || (a.seg[i].taps != 9 && a.seg[i].taps != 1) || (a.seg[i].ss_off >= 0 && !a.ss)) {
+            set_error("launch_conv_fused: bad segment %d", i);
+            return BNDM_E_ARG;
+        }
+    for (int i = 1; i < a.nseg; ++i)
+        if (a.seg[i].ss_off >= 0 && a.seg[i - 1].taps == 1) {
+            set_error("launch_conv_fused: a normalised segment may not follow a 1x1 segment");
+            return BNDM_E_ARG;
+        }
+    if (a.ss && a.ssC > 1024) {
+        set_error("launch_conv_fused: scale/shift table of %d channels exceeds 1024", a.ssC);
+        return BNDM_E_ARG;
+    }
+    static const int abl = getenv("BNDM_ABLATE") ? atoi(getenv("BNDM_ABLATE")) : 0;
+    if (dtype == BNDM_DTYPE_F16) {
+        if (abl && TH == 16) {       // profiling-only variants (f16, 256-pixel tiles)
+            switch (abl) {
+                case 1: return launch_fused_t<_Float16, 16, 1>(a, st);
+                case 2: return launch_fused_t<_Float16, 16, 2>(a, st);
+                case 4: return launch_fused_t<_Float16, 16, 4>(a, st);
+                case 8: return launch_fused_t<_Float16, 16, 8>(a, st);
+                case 7: return launch_fused_t<_Float16, 16, 7>(a, st);
+                case 15: return launch_fused_t<_Float16, 16, 15>(a, st);
+                default: break;
+            }
+        }
+        return TH == 16 ? launch_fused_t<_Float16, 16, 0>(a, st) : launch_fused_t<_Float16, 8, 0>(a, st);
+    }
+    return TH == 16 ? launch_fused_t<__bf16, 16, 0>(a, st) : launch_fused_t<__bf16, 8, 0>(a, st);
+}
+
+int launch_gn_small(int dtype, const void *x1, int C1, const void *x2, int C2, int B, int HW, int groups, float eps,
+                    const float *gamma, const float *beta, int silu, void *out, hipStream_t st) {
+    const int C = C1 + C2, CH = C / 8;
+    if (C % 8 || C1 % 8 || CH > 512 || C % groups) {
+        set_error("gn_small: unsupported channels %d+%d", C1, C2);
+        return BNDM_E_ARG;
+    }
+    const int RP = 512 / CH;
+    const size_t smem = (size_t)RP * C * 2 * 4 + (size_t)2 * C * 4;
+    if (dtype == BNDM_DTYPE_F16)
+        hipLaunchKernelGGL(gn_small_kernel<_Float16>, dim3(B), dim3(512), smem, st, (const _Float16 *)x1, C1,
+                           (const _Float16 *)x2, C2, HW, groups, eps, gamma, beta, silu, (_Float16 *)out);
+    else
+        hipLaunchKernelGGL(gn_small_kernel<__bf16>, dim3(B), dim3(512), smem, st, (const __bf16 *)x1, C1,
+                           (const __bf16 *)x2, C2, HW, groups, eps, gamma, beta, silu, (__bf16 *)out);
+    return launch_status("gn_small");
+}
+
+int launch_gn_finalize2(const float *p1, int nslab1, int C1, const float *p2, int nslab2, int C2, int B, int HW,
+                        int groups, float eps, const float *gamma, const float *beta, float *scale_shift,
+                        hipStream_t st) {
+    if (C1 + C2 > 1024 || (C1 + C2) % groups) {
+        set_error("gn_finalize2: C=%d groups=%d unsupported", C1 + C2, groups);
+        return BNDM_E_ARG;
+    }
+    hipLaunchKernelGGL(gn_finalize2_kernel, dim3(B), dim3(256), 0, st, p1, nslab1, C1, p2, nslab2, C2, HW, groups, eps,
+                       gamma, beta, scale_shift);
+    return launch_status("gn_finalize2");
+}
+
+}  // namespace bndm

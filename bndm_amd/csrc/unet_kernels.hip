@@ -14,33 +14,11 @@
 //   attention       softmax(q k^T / sqrt(8)) v for 8-wide heads over <= a few hundred tokens
 //   temb_mlp        sinusoidal Timesteps -> Linear -> SiLU -> Linear -> SiLU (fp32)
 #include "unet_kernels.hpp"
+#include "unet_types.hpp"
 #include <cmath>
 
 namespace bndm {
 namespace {
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-template <typename T> struct TT;
-template <> struct TT<_Float16> {
-    using v8 = f16x8;
-    using v4 = f16x4;
-    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-    }
-};
-template <> struct TT<__bf16> {
-    using v8 = bf16x8;
-    using v4 = bf16x4;
-    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-    }
-};
-
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
 
 // ------------------------------------------------------------------------------------------------
 // implicit-GEMM convolution
@@ -76,17 +54,22 @@ __device__ __forceinline__ void kiter_next(KIter &k, const ConvArgs &a) {
     }
 }
 
-template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int EPI>
-__global__ __launch_bounds__(256) void conv_igemm(const ConvArgs a, const int ksteps, const int logW,
-                                                  const int logH, const int ntm, const int ntn) {
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
-    constexpr int BM = WAVES_M * TM * 32;   // output pixels per block
-    constexpr int BN = WAVES_N * TN * 32;   // output channels per block
+template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int EPI, int STAGES>
+__global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvArgs a, const int ksteps,
+                                                                     const int logW, const int logH,
+                                                                     const int ntm, const int ntn) {
+    constexpr int NT = WAVES_M * WAVES_N * 64;   // threads per block
+    constexpr int RPI = NT / 8;                  // tile rows covered by one block-wide glds instruction
+    constexpr int BM = WAVES_M * TM * 32;        // output pixels per block
+    constexpr int BN = WAVES_N * TN * 32;        // output channels per block
     constexpr int X_BYTES = BM * 128;
     constexpr int W_BYTES = BN * 128;
     constexpr int STAGE = X_BYTES + W_BYTES;
-    constexpr int NXP = BM / 32;            // 16-B pieces per thread per stage (activations)
-    constexpr int NWP = BN / 32;            // (weights)
+    constexpr int NXP = BM / RPI;                // 16-B pieces per thread per stage (activations)
+    constexpr int NWP = BN / RPI;                // (weights)
+    constexpr int NLD = NXP + NWP;               // glds instructions per thread per stage
+    static_assert(BM % RPI == 0 && BN % RPI == 0, "tile rows must be a multiple of the staging stride");
+    static_assert(STAGES >= 2 && NLD * (STAGES - 1) <= 63, "vmcnt field is 6 bits");
     using v8 = typename TT<T>::v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -117,12 +100,12 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvArgs a, const int ks
     const int nsteps = max(0, ks_end - ks_begin);
 
     // ---- per-thread staging descriptors -----------------------------------------------------------
-    const int prow = tid >> 3;                       // 0..31
+    const int prow = tid >> 3;                       // 0..RPI-1
     const int lchunk = (tid & 7) ^ ((tid >> 4) & 7); // logical 16-B chunk this lane fetches
     int px[NXP], py[NXP], pb[NXP];
 #pragma unroll
     for (int i = 0; i < NXP; ++i) {
-        const int m = m0 + prow + 32 * i;
+        const int m = m0 + prow + RPI * i;
         px[i] = m & (Wd - 1);
         py[i] = (m >> logW) & (H - 1);
         pb[i] = (m < M) ? (m >> (logW + logH)) : -1;
@@ -130,7 +113,7 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvArgs a, const int ks
     const char *wsrc[NWP];
 #pragma unroll
     for (int i = 0; i < NWP; ++i)
-        wsrc[i] = (const char *)a.Wgt + ((size_t)(n0 + prow + 32 * i) * a.Ktot + lchunk * 8) * 2;
+        wsrc[i] = (const char *)a.Wgt + ((size_t)(n0 + prow + RPI * i) * a.Ktot + lchunk * 8) * 2;
 
     auto stage = [&](int buf, const KIter &k, int ks) {
         char *base = smem + buf * STAGE;
@@ -140,28 +123,25 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvArgs a, const int ks
             dy = k.tap / 3 - 1;
             dx = k.tap - (dy + 1) * 3 - 1;
         }
+        // unified addressing: coordinate c = p*mul + d is bounds-checked against lim (the upsampled /
+        // strided extent), the source pixel is c >> sh in an Hs x Ws tensor
+        const int sh = sg.up ? 1 : 0;
+        const int mul = sg.up ? 1 : a.stride;
+        const int limY = sg.up ? H : H * a.stride, limX = sg.up ? Wd : Wd * a.stride;
+        const int Hs = limY >> sh, Ws = limX >> sh;
         const int coff = k.chunk * 64 + lchunk * 8;
+        const char *sbase = (const char *)sg.src;
 #pragma unroll
         for (int i = 0; i < NXP; ++i) {
-            int iy, ix, Hs, Ws;
-            bool ok;
-            if (sg.up) {
-                const int uy = py[i] + dy, ux = px[i] + dx;
-                ok = (unsigned)uy < (unsigned)H && (unsigned)ux < (unsigned)Wd;
-                iy = uy >> 1; ix = ux >> 1; Hs = H >> 1; Ws = Wd >> 1;
-            } else {
-                iy = py[i] * a.stride + dy; ix = px[i] * a.stride + dx;
-                Hs = H * a.stride; Ws = Wd * a.stride;
-                ok = (unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws;
-            }
-            ok = ok && pb[i] >= 0;
-            const size_t off = ((size_t)((pb[i] * Hs + iy) * Ws + ix) * sg.C + coff) * 2;
-            const char *src = ok ? (const char *)sg.src + off : (const char *)a.zeros;
-            glds16(src, base + i * 4096 + w * 1024);
+            const int cy = py[i] * mul + dy, cx = px[i] * mul + dx;
+            const bool ok = (unsigned)cy < (unsigned)limY && (unsigned)cx < (unsigned)limX && pb[i] >= 0;
+            const long off = ((long)((pb[i] * Hs + (cy >> sh)) * Ws + (cx >> sh)) * sg.C + coff) * 2;
+            const char *src = ok ? sbase + off : (const char *)a.zeros;
+            glds16(src, base + i * (RPI * 128) + w * 1024);
         }
 #pragma unroll
         for (int i = 0; i < NWP; ++i)
-            glds16(wsrc[i] + (size_t)ks * 128, base + X_BYTES + i * 4096 + w * 1024);
+            glds16(wsrc[i] + (size_t)min(ks, ksteps - 1) * 128, base + X_BYTES + i * (RPI * 128) + w * 1024);
     };
 
     f32x16 acc[TN][TM];
@@ -175,19 +155,29 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvArgs a, const int ks
     const int wm = w % WAVES_M, wn = w / WAVES_M;
     const int frow = l & 31, kh = l >> 5, key = (l >> 1) & 7;
 
+    // ---- STAGES-deep ring: stages s+1 .. s+STAGES-1 are in flight while step s is multiplied.
+    // Every thread issues exactly NLD loads per stage (empty tail stages re-read the last tile into
+    // a buffer nobody will read), so "stage s has landed" is the counted wait vmcnt(NLD*(STAGES-2))
+    // after the issue of stage s+STAGES-2; one raw s_barrier per K-step both publishes stage s to all
+    // waves and retires the buffer that the next issue overwrites.
     KIter kit;
     kiter_init(kit, a, ks_begin);
-    if (nsteps > 0) {
-        stage(0, kit, ks_begin);
-        kiter_next(kit, a);
-        wait_vmem_all();
-        __syncthreads();
+    int issued = 0;
+#pragma unroll
+    for (int p = 0; p < STAGES - 1; ++p) {
+        stage(p, kit, ks_begin + (issued < nsteps ? issued : max(nsteps - 1, 0)));
+        if (issued + 1 < nsteps) kiter_next(kit, a);
+        ++issued;
     }
-    int cur = 0;
+    int cur = 0, nxt = STAGES - 1;
     for (int it = 0; it < nsteps; ++it) {
-        if (it + 1 < nsteps) {
-            stage(cur ^ 1, kit, ks_begin + it + 1);
-            kiter_next(kit, a);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (STAGES - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        {
+            stage(nxt, kit, ks_begin + (issued < nsteps ? issued : nsteps - 1));
+            if (issued + 1 < nsteps) kiter_next(kit, a);
+            ++issued;
         }
         const char *Xt = smem + cur * STAGE;
         const char *Wt = Xt + X_BYTES;
@@ -206,10 +196,10 @@ __global__ __launch_bounds__(256) void conv_igemm(const ConvArgs a, const int ks
 #pragma unroll
                 for (int j = 0; j < TM; ++j) acc[i][j] = TT<T>::mfma(af[i], bf[j], acc[i][j]);
         }
-        wait_vmem_all();
-        __syncthreads();
-        cur ^= 1;
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
+        nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dummy tail stages before exit
 
     // ---- epilogue: lane owns pixel (l&31) of each M-tile and channels 8g + 4*kh + {0..3} -----------
     const int HW = 1 << (logW + logH);
@@ -311,20 +301,21 @@ template <typename T>
 __global__ __launch_bounds__(256) void conv_in_kernel(const float *__restrict__ x, int Cx,
                                                       const float *__restrict__ extra, int Ce,
                                                       const T *__restrict__ W16, const float *__restrict__ bias,
-                                                      T *__restrict__ out, int B, int logH, int logW, int C0,
-                                                      int KP) {
+                                                      T *__restrict__ out, float *__restrict__ stats, int B,
+                                                      int logH, int logW, int C0, int KP) {
+    // block = 128 consecutive pixels of one sample (H*W is a multiple of 128); wave = 32 pixels.
+    // The tile is staged in LDS so that rows are stored 16 B per lane and the per-channel sums for the
+    // first GroupNorm come out of the same pass.
     using v8 = typename TT<T>::v8;
     using v4 = typename TT<T>::v4;
-    const int l = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
     const int H = 1 << logH, Wd = 1 << logW, HW = H * Wd;
-    const int M = B * HW;
-    const int m = wave * 32 + (l & 31);
-    if (wave * 32 >= M) return;
+    const int m0 = blockIdx.x * 128;
+    const int m = m0 + wv * 32 + (l & 31);
     const int kh = l >> 5;
     const int Cin = Cx + Ce;
-    const int mm = m < M ? m : M - 1;
-    const int xx = mm & (Wd - 1), yy = (mm >> logW) & (H - 1), b = mm >> (logW + logH);
+    const int xx = m & (Wd - 1), yy = (m >> logW) & (H - 1), b = m >> (logW + logH);
     const int nks = KP >> 4;
     v8 bf[4];
     for (int s = 0; s < 4; ++s) {
@@ -342,6 +333,8 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float *__restrict__ 
             bf[s][j] = (T)v;
         }
     }
+    const int rowB = C0 * 2;                       // bytes per staged pixel row
+    const int pl = wv * 32 + (l & 31);             // pixel inside the block
     for (int n0 = 0; n0 < C0; n0 += 32) {
         f32x16 acc;
 #pragma unroll
@@ -350,16 +343,45 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float *__restrict__ 
             const v8 af = *reinterpret_cast<const v8 *>(W16 + (size_t)(n0 + (l & 31)) * KP + 16 * s + 8 * kh);
             acc = TT<T>::mfma(af, bf[s], acc);
         }
-        if (m < M) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = n0 + 8 * g + 4 * kh;
-                const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + co);
-                v4 ov;
+        for (int g = 0; g < 4; ++g) {
+            const int co = n0 + 8 * g + 4 * kh;
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + co);
+            v4 ov;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ov[e] = (T)(acc[4 * g + e] + bv[e]);
-                *reinterpret_cast<v4 *>(out + (size_t)m * C0 + co) = ov;
-            }
+            for (int e = 0; e < 4; ++e) ov[e] = (T)(acc[4 * g + e] + bv[e]);
+            *reinterpret_cast<v4 *>(smem + pl * rowB + ((((co >> 3) ^ (pl & 15)) << 4) | ((co & 7) * 2))) = ov;
+        }
+    }
+    __syncthreads();
+    const int CH = C0 >> 3, RP = 256 / CH;         // 16-B chunks per row, pixel rows per pass
+    const int c16 = tid % CH, prw = tid / CH;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    for (int p = prw; p < 128; p += RP) {
+        const v8 v = *reinterpret_cast<const v8 *>(smem + p * rowB + ((c16 ^ (p & 15)) << 4));
+        *reinterpret_cast<v8 *>(out + (size_t)(m0 + p) * C0 + c16 * 8) = v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = (float)v[e];
+            s1[e] += f;
+            s2[e] = fmaf(f, f, s2[e]);
+        }
+    }
+    if (stats) {
+        float *red = reinterpret_cast<float *>(smem + 128 * rowB);     // [RP][C0][2]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[((prw * C0) + c16 * 8 + e) * 2 + 0] = s1[e];
+            red[((prw * C0) + c16 * 8 + e) * 2 + 1] = s2[e];
+        }
+        __syncthreads();
+        const int nslab = HW >> 7, b0 = m0 >> (logW + logH), slab = (m0 & (HW - 1)) >> 7;
+        for (int i = tid; i < 2 * C0; i += 256) {
+            float t = 0.f;
+            for (int r = 0; r < RP; ++r) t += red[r * C0 * 2 + i];
+            stats[((size_t)(b0 * nslab + slab) * C0) * 2 + i] = t;
         }
     }
 }
@@ -529,6 +551,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const T *__restrict__ qk
 // ------------------------------------------------------------------------------------------------
 // time embedding MLP (fp32): act_emb = SiLU(W2 SiLU(W1 [cos|sin](t f) + b1) + b2)
 // ------------------------------------------------------------------------------------------------
+// grid (D/64, B): each block recomputes the 128->D hidden layer of its sample (cheap) and produces 64
+// outputs of the second layer with 4 k-slices per output (coalesced reads of the transposed weights).
 template <typename T>
 __global__ __launch_bounds__(256) void temb_mlp_kernel(const float *__restrict__ t, int C0, int D,
                                                        const float *__restrict__ W1t, const float *__restrict__ b1,
@@ -536,26 +560,33 @@ __global__ __launch_bounds__(256) void temb_mlp_kernel(const float *__restrict__
                                                        T *__restrict__ act) {
     __shared__ float emb[256];
     __shared__ float h1[1024];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ float part[4][64];
+    const int b = blockIdx.y, n0 = blockIdx.x * 64, tid = threadIdx.x;
     const float tv = t[b];
     const int half = C0 >> 1;
-    for (int i = tid; i < C0; i += blockDim.x) {
+    for (int i = tid; i < C0; i += 256) {
         const int k = i < half ? i : i - half;
         const float f = expf(-9.210340371976184f * (float)k / (float)half);   // ln(10000)
         const float ang = tv * f;
         emb[i] = i < half ? cosf(ang) : sinf(ang);                            // flip_sin_to_cos
     }
     __syncthreads();
-    for (int n = tid; n < D; n += blockDim.x) {
+    for (int n = tid; n < D; n += 256) {
         float s = b1[n];
+#pragma unroll 8
         for (int k = 0; k < C0; ++k) s = fmaf(emb[k], W1t[(size_t)k * D + n], s);
         h1[n] = s / (1.0f + expf(-s));
     }
     __syncthreads();
-    for (int n = tid; n < D; n += blockDim.x) {
-        float s = b2[n];
-        for (int k = 0; k < D; ++k) s = fmaf(h1[k], W2t[(size_t)k * D + n], s);
-        act[(size_t)b * D + n] = (T)(s / (1.0f + expf(-s)));
+    const int nl = tid & 63, ksl = tid >> 6, kper = D >> 2;
+    float s = 0.f;
+#pragma unroll 8
+    for (int k = ksl * kper; k < (ksl + 1) * kper; ++k) s = fmaf(h1[k], W2t[(size_t)k * D + n0 + nl], s);
+    part[ksl][nl] = s;
+    __syncthreads();
+    if (tid < 64) {
+        const float v = b2[n0 + tid] + ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
+        act[(size_t)b * D + n0 + tid] = (T)(v / (1.0f + expf(-v)));
     }
 }
 
@@ -565,34 +596,38 @@ inline int ilog2(int v) {
     return r;
 }
 
-template <typename T, int WM, int WN, int TM, int TN, int EPI>
+template <typename T, int WM, int WN, int TM, int TN, int EPI, int STAGES>
 int launch_conv_cfg(const ConvArgs &a, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int smem = 2 * (BM + BN) * 128;
+    constexpr int smem = STAGES * (BM + BN) * 128;
     int ksteps = 0;
     for (int i = 0; i < a.nseg; ++i) ksteps += a.seg[i].taps * (a.seg[i].C / 64);
     const int M = a.B * a.H * a.W;
     const int ntm = ceil_div(M, BM), ntn = ceil_div(a.Cout, BN);
     static bool attr = false;
     if (!attr) {
-        BNDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm<T, WM, WN, TM, TN, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        BNDM_CHECK_HIP(hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&conv_igemm<T, WM, WN, TM, TN, EPI, STAGES>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr = true;
     }
     dim3 grid(ntm * ntn, a.splitk > 1 ? a.splitk : 1);
-    hipLaunchKernelGGL((conv_igemm<T, WM, WN, TM, TN, EPI>), grid, dim3(256), smem, st, a, ksteps, ilog2(a.W),
-                       ilog2(a.H), ntm, ntn);
+    hipLaunchKernelGGL((conv_igemm<T, WM, WN, TM, TN, EPI, STAGES>), grid, dim3(WM * WN * 64), smem, st, a, ksteps,
+                       ilog2(a.W), ilog2(a.H), ntm, ntn);
     return launch_status("conv_igemm");
 }
 
 template <typename T>
 int launch_conv_t(int tile, int epi, const ConvArgs &a, hipStream_t st) {
-    if (tile == TILE_128x128) {
-        if (epi == EPI_NHWC16) return launch_conv_cfg<T, 2, 2, 2, 2, EPI_NHWC16>(a, st);
-        if (epi == EPI_F32_ROWS) return launch_conv_cfg<T, 2, 2, 2, 2, EPI_F32_ROWS>(a, st);
-    } else if (tile == TILE_128x32) {
-        if (epi == EPI_NCHW32) return launch_conv_cfg<T, 4, 1, 1, 1, EPI_NCHW32>(a, st);
-        if (epi == EPI_NHWC16) return launch_conv_cfg<T, 4, 1, 1, 1, EPI_NHWC16>(a, st);
+    if (tile == TILE_256x128) {      // 8 waves, 3-stage ring (144 KB LDS, one block per CU)
+        if (epi == EPI_NHWC16) return launch_conv_cfg<T, 4, 2, 2, 2, EPI_NHWC16, 3>(a, st);
+        if (epi == EPI_F32_ROWS) return launch_conv_cfg<T, 4, 2, 2, 2, EPI_F32_ROWS, 3>(a, st);
+    } else if (tile == TILE_128x128) {   // 4 waves, 4-stage ring (128 KB LDS)
+        if (epi == EPI_NHWC16) return launch_conv_cfg<T, 2, 2, 2, 2, EPI_NHWC16, 4>(a, st);
+        if (epi == EPI_F32_ROWS) return launch_conv_cfg<T, 2, 2, 2, 2, EPI_F32_ROWS, 4>(a, st);
+    } else if (tile == TILE_128x32) {    // 4 waves, 4-stage ring (80 KB LDS)
+        if (epi == EPI_NCHW32) return launch_conv_cfg<T, 4, 1, 1, 1, EPI_NCHW32, 4>(a, st);
+        if (epi == EPI_NHWC16) return launch_conv_cfg<T, 4, 1, 1, 1, EPI_NHWC16, 4>(a, st);
     }
     set_error("launch_conv: unsupported tile/epilogue combination %d/%d", tile, epi);
     return BNDM_E_ARG;
@@ -631,17 +666,24 @@ int launch_splitk_reduce(int dtype, const float *part, int splitk, const ConvArg
 }
 
 int launch_conv_in(int dtype, const float *x, int Cx, const float *extra, int Ce, const void *W16, const float *bias,
-                   void *out, int B, int H, int W, int C0, int KP, hipStream_t st) {
+                   void *out, float *stats, int B, int H, int W, int C0, int KP, hipStream_t st) {
     const int M = B * H * W;
-    const int blocks = ceil_div(ceil_div(M, 32), 4);
+    if ((H * W) % 128 || (C0 != 64 && C0 != 128 && C0 != 256)) {
+        set_error("conv_in: H*W=%d must be a multiple of 128 and C0=%d one of 64/128/256", H * W, C0);
+        return BNDM_E_ARG;
+    }
+    const int blocks = M / 128;
+    const int smem = 128 * C0 * 2 + (256 / (C0 / 8)) * C0 * 2 * 4;
     if (dtype == BNDM_DTYPE_F16)
-        hipLaunchKernelGGL(conv_in_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, x, Cx, extra, Ce,
-                           (const _Float16 *)W16, bias, (_Float16 *)out, B, ilog2(H), ilog2(W), C0, KP);
+        hipLaunchKernelGGL(conv_in_kernel<_Float16>, dim3(blocks), dim3(256), smem, st, x, Cx, extra, Ce,
+                           (const _Float16 *)W16, bias, (_Float16 *)out, stats, B, ilog2(H), ilog2(W), C0, KP);
     else
-        hipLaunchKernelGGL(conv_in_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, x, Cx, extra, Ce,
-                           (const __bf16 *)W16, bias, (__bf16 *)out, B, ilog2(H), ilog2(W), C0, KP);
+        hipLaunchKernelGGL(conv_in_kernel<__bf16>, dim3(blocks), dim3(256), smem, st, x, Cx, extra, Ce,
+                           (const __bf16 *)W16, bias, (__bf16 *)out, stats, B, ilog2(H), ilog2(W), C0, KP);
     return launch_status("conv_in");
 }
+
+int conv_tile_bm(int tile) { return tile == TILE_256x128 ? 256 : 128; }
 
 int gn_num_slabs(int HW) {
     int n = HW / 256;
@@ -701,15 +743,16 @@ int launch_attention(int dtype, const void *qkv, void *out, int B, int T, int C,
 
 int launch_temb_mlp(int dtype, const float *t, int B, int C0, int D, const float *W1t, const float *b1,
                     const float *W2t, const float *b2, void *act_emb16, hipStream_t st) {
-    if (C0 > 256 || D > 1024) {
+    if (C0 > 256 || D > 1024 || D % 64) {
         set_error("temb_mlp: C0=%d D=%d unsupported", C0, D);
         return BNDM_E_ARG;
     }
+    const dim3 grid(D / 64, B);
     if (dtype == BNDM_DTYPE_F16)
-        hipLaunchKernelGGL(temb_mlp_kernel<_Float16>, dim3(B), dim3(256), 0, st, t, C0, D, W1t, b1, W2t, b2,
+        hipLaunchKernelGGL(temb_mlp_kernel<_Float16>, grid, dim3(256), 0, st, t, C0, D, W1t, b1, W2t, b2,
                            (_Float16 *)act_emb16);
     else
-        hipLaunchKernelGGL(temb_mlp_kernel<__bf16>, dim3(B), dim3(256), 0, st, t, C0, D, W1t, b1, W2t, b2,
+        hipLaunchKernelGGL(temb_mlp_kernel<__bf16>, grid, dim3(256), 0, st, t, C0, D, W1t, b1, W2t, b2,
                            (__bf16 *)act_emb16);
     return launch_status("temb_mlp");
 }

@@ -3,6 +3,7 @@
 // embeddings and accumulators are fp32.
 #pragma once
 #include "common.hpp"
+#include <vector>
 
 namespace bndm {
 
@@ -36,7 +37,8 @@ struct ConvArgs {
 };
 
 enum ConvEpilogue { EPI_NHWC16 = 0, EPI_F32_ROWS = 1, EPI_NCHW32 = 2 };
-enum ConvTile { TILE_128x128 = 0, TILE_128x32 = 1 };
+enum ConvTile { TILE_128x128 = 0, TILE_128x32 = 1, TILE_256x128 = 2 };
+int conv_tile_bm(int tile);
 
 int launch_conv(int dtype, int tile, int epi, const ConvArgs &a, hipStream_t st);
 
@@ -45,8 +47,9 @@ int launch_splitk_reduce(int dtype, const float *part, int splitk, const ConvArg
 
 // conv_in: fp32 NCHW sample (+ optional extra fp32 NCHW tensor concatenated on channels) -> NHWC 16-bit
 // W16 is [C0][KP] 16-bit with k = ci*9 + ky*3 + kx, zero-padded to KP (multiple of 16, <= 64)
+// stats (optional): GroupNorm partial sums [B][H*W/128][C0][2] of the stored values
 int launch_conv_in(int dtype, const float *x, int Cx, const float *extra, int Ce, const void *W16,
-                   const float *bias, void *out, int B, int H, int W, int C0, int KP, hipStream_t st);
+                   const float *bias, void *out, float *stats, int B, int H, int W, int C0, int KP, hipStream_t st);
 
 // GroupNorm(32) statistics of cat(x1, x2) -> per-(sample, channel) scale/shift
 //   y = x * scale[b][c] + shift[b][c]  ==  (x - mean_g) * rstd_g * gamma_c + beta_c
@@ -102,11 +105,19 @@ struct FusedArgs {
     void *out;           // NHWC 16-bit
     float *stats;        // [B][tiles_per_sample][Cout][2] or nullptr
     int B, H, W, Cout;
+    const void *zeros;   // >= 16 bytes of zeros (source of padding pieces)
+    const void *steps;   // device copy of build_fused_steps(seg, nseg, TH)
 };
 
 // TH = 16 (256-pixel tiles) or 8 (128-pixel tiles); W must be a multiple of 16, H of TH
 int launch_conv_fused(int dtype, int TH, const FusedArgs &a, hipStream_t st);
 int conv_fused_tiles_per_sample(int TH, int H, int W);
+// per-step schedule table of conv_fused (host side; upload and pass as FusedArgs::steps)
+std::vector<int> build_fused_steps(const FusedSeg *seg, int nseg, int TH);
+
+// one-launch GroupNorm(+SiLU) for small per-sample tensors (statistics + apply, one block per sample)
+int launch_gn_small(int dtype, const void *x1, int C1, const void *x2, int C2, int B, int HW, int groups, float eps,
+                    const float *gamma, const float *beta, int silu, void *out, hipStream_t st);
 
 // two-source variant of gn_finalize: statistics of cat(x1, x2) from per-tensor partial sums
 int launch_gn_finalize2(const float *p1, int nslab1, int C1, const float *p2, int nslab2, int C2, int B, int HW,
