@@ -453,6 +453,16 @@ struct Builder {
         a.Cout = out.C;
         a.Ktot = Ktot;
         a.zeros = h->zeros;
+        {
+            bool any_up = false;
+            for (int i = 0; i < a.nseg; ++i) any_up = any_up || a.seg[i].up;
+            if (!any_up) {
+                const std::vector<int> tab = build_conv_steps(a.seg, a.nseg, out.W, stride);
+                void *dtab;
+                if ((rc = upload(h, tab.data(), tab.size() * sizeof(int), &dtab))) return;
+                a.steps = dtab;
+            }
+        }
         const int rs = resid ? resid->slot : -1, so = out.slot;
         stats_of.erase(out.slot);
         const int ksteps = Ktot / 64;

@@ -22,7 +22,7 @@ namespace {
 
 // One int4 per K-step, built on the host (build_fused_steps) so the device loop carries no iterator
 // state, no segment-table loads and almost no scalar bookkeeping:
-//   x  weight k-offset (elements) of step s+2 (clamped)        -> weight DMA issued in the even phase of s
+//   x  weight k-offset (elements) of step s+3 (clamped)        -> weight DMA issued in the even phase of s
 //   y  read descriptor of step s: tap offset (ky*18+kx) | patch buffer << 16
 //   z  patch DMA: bit31 issue after the weight DMA (chunk with 8 steps of slack), bit30 issue before it
 //      (raw 1x1 chunk needed next step) | segment << 24 | buffer << 23 | chunk
@@ -43,12 +43,13 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
     constexpr int TW = 16, PW = TW + 2, PH = TH + 2;
     constexpr int NPP = PH * PW;                       // patch pixels
     constexpr int NPIECE = NPP * 8;                    // 16-byte pieces per patch chunk
-    constexpr int NROUND = (NPIECE + 511) / 512;       // patch DMAs per thread per chunk
-    constexpr int PATCH_BYTES = NROUND * 8192;         // rounded up: tail lanes of the last round land in dead space
+    constexpr int NROUND = (NPIECE + 511) / 512;       // patch DMA rounds per chunk (the last one is partial)
+    constexpr int NREMW = (NPIECE - (NROUND - 1) * 512 + 63) / 64;   // waves that take part in the last round
+    constexpr int PATCH_BYTES = (NROUND - 1) * 8192 + NREMW * 1024;
     constexpr int BM = TH * TW;
     constexpr int TM = TH / 8;                         // 32-pixel MFMA tiles per wave along M
     constexpr int TN = 2;
-    constexpr int WSTAGES = 3;
+    constexpr int WSTAGES = 4;
     constexpr int W_BYTES = 128 * 128;
     constexpr int OFF_W = 2 * PATCH_BYTES;
     constexpr int OFF_SS = OFF_W + WSTAGES * W_BYTES;
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
 
     // ---- patch piece descriptors (independent of the chunk) ----------------------------------------
     int p_lds[NROUND], p_full[NROUND], p_half[NROUND], p_lc[NROUND];
+    int p_valid = 0;                                   // bit r: piece of round r is inside the image
 #pragma unroll
     for (int r = 0; r < NROUND; ++r) {
         const int piece = r * 512 + tid;
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
         p_lc[r] = pch ^ ((pp >> 1) & 7);
         p_full[r] = ok ? (b * H + iy) * Wd + ix : -1;
         p_half[r] = ok ? (b * (H >> 1) + (iy >> 1)) * (Wd >> 1) + (ix >> 1) : -1;
+        p_valid |= ok ? (1 << r) : 0;
     }
     // The patch of a chunk goes by LDS-DMA straight into its LDS buffer (piece index == LDS order, the
     // XOR swizzle sits on the source side).  Every thread issues exactly NROUND DMAs per chunk (tail
@@ -113,36 +116,49 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
         char *P = smem + buf * PATCH_BYTES;
 #pragma unroll
         for (int r = 0; r < NROUND; ++r) {
+            if (r == NROUND - 1 && w >= NREMW) break;     // wave-uniform: this wave owns no piece of the last round
             const int pix = sg.up ? p_half[r] : p_full[r];
             const char *src = pix >= 0 ? sbase + ((size_t)pix * sg.C + chunk * 64 + p_lc[r] * 8) * 2
                                        : (const char *)a.zeros;
             glds16(src, P + r * 8192 + w * 1024);
         }
     };
-    // GroupNorm scale/shift + SiLU applied in place to this thread's own piece of round `round`
-    // (padding pieces stay zero: the reference pads AFTER the activation)
-    auto patch_xform = [&](int sidx, int chunk, int buf, int round) {
-        const FusedSeg sg = seg_of(sidx);
-        char *P = smem + buf * PATCH_BYTES;
+    const bool last_round_wave = w < NREMW;            // wave-uniform
+    // GroupNorm scale/shift + SiLU applied in place to this thread's own piece of a round.  Branch-free
+    // (everything is derived from the wave-uniform round number plus the validity bitmask; padding and
+    // tail pieces are rewritten unchanged -- the reference pads AFTER the activation) so that the
+    // arithmetic can sit in the same basic block as the MFMAs and be interleaved with them.
+    struct XfRegs {
+        v8 v;
+        f32x4 s0, s1, h0, h1;
+        char *addr;
+        bool valid;
+    };
+    auto xf_load = [&](int xd, XfRegs &x) {
+        const int round = (xd >> 16) & 7, chunk = xd & 0xffff, buf = (xd >> 23) & 1;
+        const int ss_off = seg_of((xd >> 24) & 3).ss_off;
+        const int piece = round * 512 + tid;
+        const int lc = (piece & 7) ^ ((piece >> 4) & 7);                 // pch ^ ((pp >> 1) & 7), pp = piece >> 3
+        x.addr = smem + buf * PATCH_BYTES + piece * 16;
+        x.valid = (p_valid >> round) & 1;
+        x.v = *reinterpret_cast<const v8 *>(x.addr);
+        const float *sc = ssL + ss_off + chunk * 64 + lc * 8;
+        const float *sh = sc + a.ssC;
+        x.s0 = *reinterpret_cast<const f32x4 *>(sc);
+        x.s1 = *reinterpret_cast<const f32x4 *>(sc + 4);
+        x.h0 = *reinterpret_cast<const f32x4 *>(sh);
+        x.h1 = *reinterpret_cast<const f32x4 *>(sh + 4);
+    };
+    auto xf_math_store = [&](const XfRegs &x) {
+        v8 o;
 #pragma unroll
-        for (int r = 0; r < NROUND; ++r) {
-            if (r != round) continue;
-            const int pix = sg.up ? p_half[r] : p_full[r];
-            if (p_lds[r] < 0 || pix < 0) continue;
-            const v8 v = *reinterpret_cast<const v8 *>(P + p_lds[r]);
-            const float *sc = ssL + sg.ss_off + chunk * 64 + p_lc[r] * 8;
-            const float *sh = sc + a.ssC;
-            const f32x4 s0 = *reinterpret_cast<const f32x4 *>(sc), s1 = *reinterpret_cast<const f32x4 *>(sc + 4);
-            const f32x4 h0 = *reinterpret_cast<const f32x4 *>(sh), h1 = *reinterpret_cast<const f32x4 *>(sh + 4);
-            v8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float f = fmaf((float)v[e], e < 4 ? s0[e & 3] : s1[e & 3], e < 4 ? h0[e & 3] : h1[e & 3]);
-                // SiLU with hardware exp2 / rcp (every normalised segment of this kernel is followed by SiLU)
-                o[e] = (T)(f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f)));
-            }
-            *reinterpret_cast<v8 *>(P + p_lds[r]) = o;
+        for (int e = 0; e < 8; ++e) {
+            const float f = fmaf((float)x.v[e], e < 4 ? x.s0[e & 3] : x.s1[e & 3], e < 4 ? x.h0[e & 3] : x.h1[e & 3]);
+            // SiLU with hardware exp2 / rcp (every normalised segment of this kernel is followed by SiLU)
+            const float g = f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f));
+            o[e] = x.valid ? (T)g : x.v[e];
         }
+        *reinterpret_cast<v8 *>(x.addr) = o;
     };
 
     // ---- weight tile staging: 128 rows x 128 B = 1024 pieces, 2 per thread ---------------------------
@@ -224,59 +240,99 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
                 for (int j = 0; j < TM; ++j) acc[i][j] = TT<T>::mfma(fa[ks][i], fb[ks][j], acc[i][j]);
         __builtin_amdgcn_s_setprio(0);
     };
-    // work common to both groups at the start of the even phase of a step
-    auto even_common = [&](const StepDesc &d, int wnext) -> bool {
-        if (!(ABL & 8) && d.w < 0) {                    // one normalisation round, in place
-            if (d.w & (1 << 30)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // patch DMA is the youngest
-            patch_xform((d.w >> 24) & 3, d.w & 0xffff, (d.w >> 23) & 1, (d.w >> 16) & 7);
+    // DMA work of the even phase of a step (returns true if a slack patch DMA followed the weight DMA)
+    // returns 0: only the weight tile, 1: a slack patch DMA followed it, 2: a late 1x1 patch DMA preceded it
+    auto even_dma = [&](const StepDesc &d, int wnext) -> int {
+        int kind = 0;
+        if (!(ABL & 8) && (d.z & (1 << 30))) {
+            patch_dma((d.z >> 24) & 3, d.z & 0xffff, (d.z >> 23) & 1);
+            kind = 2;
         }
-        if (!(ABL & 8) && (d.z & (1 << 30))) patch_dma((d.z >> 24) & 3, d.z & 0xffff, (d.z >> 23) & 1);
         asm volatile("" ::: "memory");
         if (!(ABL & 2)) w_issue(wnext, d.x);
         asm volatile("" ::: "memory");
         if (!(ABL & 8) && d.z < 0) {
             patch_dma((d.z >> 24) & 3, d.z & 0xffff, (d.z >> 23) & 1);
             asm volatile("" ::: "memory");
-            return true;
+            kind = 1;
         }
-        return false;
+        return kind;
     };
 
     const bool grpA = wn == 0;                         // wave-uniform (w is an SGPR)
     StepDesc dcur = steps[0];
     StepDesc dnext = steps[nsteps > 1 ? 1 : 0];
 
-    // ---- prologue: chunk 0 and weight tiles 0, 1 in flight together; then normalise chunk 0 ------------
+    // ---- prologue: chunk 0 and the first WSTAGES-1 weight tiles in flight together; normalise chunk 0 ----
     patch_dma(0, 0, 0);
-    w_issue(0, steps[nsteps].x);                        // the table carries the k-offsets of steps 0 / 1 at the end
+    asm volatile("" ::: "memory");
+    w_issue(0, steps[nsteps].x);                        // the table's extra entry carries the k-offsets of steps 0..2
     w_issue(1, steps[nsteps].y);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // own patch pieces landed (weights may still fly)
+    w_issue(2, steps[nsteps].z);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // own patch pieces landed (weights may still fly)
     __syncthreads();                                   // ss table visible (written above by plain stores)
     if (a.seg[0].ss_off >= 0) {
-#pragma unroll
-        for (int r = 0; r < NROUND; ++r) patch_xform(0, 0, 0, r);
+        for (int r = 0; r < NROUND; ++r) {
+            if (r == NROUND - 1 && !last_round_wave) break;
+            XfRegs x;
+            xf_load(r << 16, x);
+            xf_math_store(x);
+        }
     }
-    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    int wcur = 0, wnext = 2;
+    int wcur = 0, wnext = WSTAGES - 1;
     if (grpA) {
         read_frags(dcur.y, 0);
         for (int s = 0; s < nsteps; ++s) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            const bool issued = even_common(dcur, wnext);
-            multiply();
-            if (issued) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 + NROUND) : "memory");
-            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            // descriptor of step s+2: issued now so that its latency hides under this phase
+            const StepDesc dn2 = steps[s + 2 < nsteps ? s + 2 : nsteps - 1];
+            // (rounds start two taps after the patch DMA: only one younger weight tile is in flight then)
+            const bool dox = !(ABL & 8) && dcur.w < 0 && (last_round_wave || ((dcur.w >> 16) & 7) != NROUND - 1);
+            if (!(ABL & 16) && dox && (dcur.w & (1 << 30))) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // patch DMA landed
+            const int issued = even_dma(dcur, wnext);
+            if (dox) {
+                // normalisation arithmetic rides in the shadow of the matrix pipe
+                XfRegs x;
+                xf_load(dcur.w, x);
+                if (ABL & 1) {
+                    multiply();
+                    xf_math_store(x);
+                } else {
+                    // no s_setprio here: it would fence the scheduler and keep the VALU work behind the MFMAs
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int i = 0; i < TN; ++i)
+#pragma unroll
+                            for (int j = 0; j < TM; ++j) acc[i][j] = TT<T>::mfma(fa[ks][i], fb[ks][j], acc[i][j]);
+                    xf_math_store(x);
+#pragma unroll
+                    for (int g = 0; g < 4 * TN * TM; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, TM == 2 ? 4 : 8, 0);    // VALU in its shadow
+                    }
+                }
+            } else {
+                multiply();
+            }
+            // weight tile s+1 landed: WSTAGES-2 younger tiles (+ a patch DMA issued after them) may still fly
+            if (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // profiling: never wait for DMA
+            else if (issued == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (WSTAGES - 2)) : "memory");
+            else if (issued == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");   // late patch: only the newest tile may fly
+            else if (last_round_wave) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (WSTAGES - 2) + NROUND) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (WSTAGES - 2) + NROUND - 1) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const int wn1 = wcur + 1 == WSTAGES ? 0 : wcur + 1;
             if (!(ABL & 4) && s + 1 < nsteps) read_frags(dnext.y, wn1);
             dcur = dnext;
-            dnext = steps[s + 2 < nsteps ? s + 2 : nsteps - 1];
+            dnext = dn2;
             wcur = wn1;
             wnext = wnext + 1 == WSTAGES ? 0 : wnext + 1;
         }
@@ -285,15 +341,30 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            const bool issued = even_common(dcur, wnext);
-            if (!(ABL & 4)) read_frags(dcur.y, wcur);
-            if (issued) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 + NROUND) : "memory");
-            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            const StepDesc dn2 = steps[s + 2 < nsteps ? s + 2 : nsteps - 1];
+            const bool dox = !(ABL & 8) && dcur.w < 0 && (last_round_wave || ((dcur.w >> 16) & 7) != NROUND - 1);
+            if (!(ABL & 16) && dox && (dcur.w & (1 << 30))) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            const int issued = even_dma(dcur, wnext);
+            if (dox) {
+                // fragment reads first, normalisation arithmetic while they are in flight
+                XfRegs x;
+                xf_load(dcur.w, x);
+                if (!(ABL & 4)) read_frags(dcur.y, wcur);
+                xf_math_store(x);
+            } else {
+                if (!(ABL & 4)) read_frags(dcur.y, wcur);
+            }
+            // weight tile s+1 landed: WSTAGES-2 younger tiles (+ a patch DMA issued after them) may still fly
+            if (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // profiling: never wait for DMA
+            else if (issued == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (WSTAGES - 2)) : "memory");
+            else if (issued == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");   // late patch: only the newest tile may fly
+            else if (last_round_wave) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (WSTAGES - 2) + NROUND) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (WSTAGES - 2) + NROUND - 1) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             multiply();
             dcur = dnext;
-            dnext = steps[s + 2 < nsteps ? s + 2 : nsteps - 1];
+            dnext = dn2;
             wcur = wcur + 1 == WSTAGES ? 0 : wcur + 1;
             wnext = wnext + 1 == WSTAGES ? 0 : wnext + 1;
         }
@@ -378,8 +449,9 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
 
 template <typename T, int TH, int ABL>
 int launch_fused_t(const FusedArgs &a, hipStream_t st) {
-    constexpr int PATCH_BYTES = (((TH + 2) * 18 * 8 + 511) / 512) * 8192;
-    constexpr int main_bytes = 2 * PATCH_BYTES + 3 * 16384 + 8192;
+    constexpr int NPIECE = (TH + 2) * 18 * 8, NROUND = (NPIECE + 511) / 512;
+    constexpr int PATCH_BYTES = (NROUND - 1) * 8192 + ((NPIECE - (NROUND - 1) * 512 + 63) / 64) * 1024;
+    constexpr int main_bytes = 2 * PATCH_BYTES + 4 * 16384 + 8192;
     constexpr int epi_bytes = TH * 16 * 256 + 32 * 128 * 2 * 4;
     constexpr int smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
     static bool attr = false;
@@ -397,31 +469,32 @@ int launch_fused_t(const FusedArgs &a, hipStream_t st) {
     return launch_status("conv_fused");
 }
 
-// cat(x1, x2) statistics from per-tensor partial sums
-__global__ __launch_bounds__(256) void gn_finalize2_kernel(const float *__restrict__ p1, int nslab1, int C1,
+// cat(x1, x2) statistics from per-tensor partial sums; a block owns 4 groups of one sample: grid (8, B)
+__global__ __launch_bounds__(128) void gn_finalize2_kernel(const float *__restrict__ p1, int nslab1, int C1,
                                                            const float *__restrict__ p2, int nslab2, int C2, int HW,
                                                            int groups, float eps, const float *__restrict__ gamma,
                                                            const float *__restrict__ beta,
                                                            float *__restrict__ scale_shift) {
-    __shared__ double cs[1024], css[1024];
-    const int b = blockIdx.x, C = C1 + C2;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    __shared__ float cs[256], css[256];
+    const int sub = blockIdx.x, b = blockIdx.y, C = C1 + C2, Cb = C >> 3;
+    for (int cl = threadIdx.x; cl < Cb; cl += blockDim.x) {
+        const int c = sub * Cb + cl;
         const float *p;
         int ns, Cs, cc;
         if (c < C1) { p = p1; ns = nslab1; Cs = C1; cc = c; } else { p = p2; ns = nslab2; Cs = C2; cc = c - C1; }
-        double s = 0, q = 0;
+        float s = 0, q = 0;
         for (int k = 0; k < ns; ++k) {
-            const float *pp = p + ((size_t)(b * ns + k) * Cs + cc) * 2;
-            s += pp[0];
-            q += pp[1];
+            const float2 v = *reinterpret_cast<const float2 *>(p + ((size_t)(b * ns + k) * Cs + cc) * 2);
+            s += v.x;
+            q += v.y;
         }
-        cs[c] = s;
-        css[c] = q;
+        cs[cl] = s;
+        css[cl] = q;
     }
     __syncthreads();
     const int Cg = C / groups;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int g0 = (c / Cg) * Cg;
+    for (int cl = threadIdx.x; cl < Cb; cl += blockDim.x) {
+        const int g0 = (cl / Cg) * Cg, c = sub * Cb + cl;
         double s = 0, q = 0;
         for (int k = 0; k < Cg; ++k) {
             s += cs[g0 + k];
@@ -438,27 +511,28 @@ __global__ __launch_bounds__(256) void gn_finalize2_kernel(const float *__restri
     }
 }
 
-// GroupNorm(32) (+SiLU) of cat(x1, x2) for one whole sample per block: statistics and application in
-// one launch (the low-resolution layers, where a sample's tensor is at most ~100 KB and stays in L2).
+// GroupNorm(32) (+SiLU) of cat(x1, x2) for the low-resolution layers (a sample's tensor is at most
+// ~100 KB and stays in L2): statistics and application in ONE launch.  Groups are independent, so a
+// block owns 4 groups (C/8 channels) of one sample: grid (8, B).
 template <typename T>
-__global__ __launch_bounds__(512) void gn_small_kernel(const T *__restrict__ x1, int C1, const T *__restrict__ x2,
+__global__ __launch_bounds__(256) void gn_small_kernel(const T *__restrict__ x1, int C1, const T *__restrict__ x2,
                                                        int C2, int HW, int groups, float eps,
                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
                                                        int silu, T *__restrict__ out) {
     using v8 = typename TT<T>::v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int C = C1 + C2, CH = C >> 3, RP = 512 / CH;
-    float *red = reinterpret_cast<float *>(smem);                 // [RP][C][2]
-    float *ss = red + (size_t)RP * C * 2;                         // [2][C]
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int chunk = tid % CH, prow = tid / CH;
-    const int c0 = chunk * 8;
+    const int C = C1 + C2, Cb = C >> 3, CHb = Cb >> 3, RP = 256 / CHb;   // channels / 16-B chunks of this block
+    float *red = reinterpret_cast<float *>(smem);                 // [RP][Cb][2]
+    float *ss = red + (size_t)RP * Cb * 2;                        // [2][Cb]
+    const int sub = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int chunk = tid % CHb, prow = tid / CHb;
+    const int cl = chunk * 8, c0 = sub * Cb + cl;                 // local / global first channel of this thread
     const T *src = c0 < C1 ? x1 + (size_t)b * HW * C1 + c0 : x2 + (size_t)b * HW * C2 + (c0 - C1);
     const int Cs = c0 < C1 ? C1 : C2;
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-    if (prow < RP)
+    if (prow < RP) {
         for (int p = prow; p < HW; p += RP) {
             const v8 v = *reinterpret_cast<const v8 *>(src + (size_t)p * Cs);
 #pragma unroll
@@ -468,34 +542,33 @@ __global__ __launch_bounds__(512) void gn_small_kernel(const T *__restrict__ x1,
                 s2[e] = fmaf(f, f, s2[e]);
             }
         }
-    if (prow < RP) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            red[((size_t)prow * C + c0 + e) * 2 + 0] = s1[e];
-            red[((size_t)prow * C + c0 + e) * 2 + 1] = s2[e];
+            red[((size_t)prow * Cb + cl + e) * 2 + 0] = s1[e];
+            red[((size_t)prow * Cb + cl + e) * 2 + 1] = s2[e];
         }
     }
     __syncthreads();
-    for (int i = tid; i < 2 * C; i += 512) {                       // per-channel totals in row 0
+    for (int i = tid; i < 2 * Cb; i += 256) {                      // per-channel totals into row 0
         float t = red[i];
-        for (int r = 1; r < RP; ++r) t += red[(size_t)r * C * 2 + i];
+        for (int r = 1; r < RP; ++r) t += red[(size_t)r * Cb * 2 + i];
         red[i] = t;
     }
     __syncthreads();
     const int Cg = C / groups;
-    for (int c = tid; c < C; c += 512) {
+    for (int c = tid; c < Cb; c += 256) {
         const int g0 = (c / Cg) * Cg;
-        double s = 0, q = 0;
+        double sm = 0, q = 0;
         for (int k = 0; k < Cg; ++k) {
-            s += red[(g0 + k) * 2];
+            sm += red[(g0 + k) * 2];
             q += red[(g0 + k) * 2 + 1];
         }
-        const double n = (double)Cg * HW, mean = s / n;
+        const double n = (double)Cg * HW, mean = sm / n;
         double var = q / n - mean * mean;
         var = var > 0 ? var : 0;
-        const float sc = (float)(1.0 / sqrt(var + (double)eps)) * gamma[c];
+        const float sc = (float)(1.0 / sqrt(var + (double)eps)) * gamma[sub * Cb + c];
         ss[c] = sc;
-        ss[C + c] = beta[c] - (float)mean * sc;
+        ss[Cb + c] = beta[sub * Cb + c] - (float)mean * sc;
     }
     __syncthreads();
     if (prow < RP)
@@ -504,7 +577,7 @@ __global__ __launch_bounds__(512) void gn_small_kernel(const T *__restrict__ x1,
             v8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float f = fmaf((float)v[e], ss[c0 + e], ss[C + c0 + e]);
+                float f = fmaf((float)v[e], ss[cl + e], ss[Cb + cl + e]);
                 if (silu) f = f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f));
                 o[e] = (T)f;
             }
@@ -535,7 +608,7 @@ std::vector<int> build_fused_steps(const FusedSeg *seg, int nseg, int TH) {
     for (int s = 0; s < n; ++s) {
         const St &c = st[s];
         int *d = &out[(size_t)s * 4];
-        d[0] = st[std::min(s + 2, n - 1)].kofs;
+        d[0] = st[std::min(s + 3, n - 1)].kofs;          // weight tile issued at step s: ring depth 4
         const int ky = c.taps == 9 ? c.tap / 3 : 1, kx = c.taps == 9 ? c.tap % 3 : 1;
         d[1] = (ky * PW + kx) | ((c.cidx & 1) << 16);
         // chunk DMA'd at tap 0 of its 9-tap predecessor
@@ -548,16 +621,17 @@ std::vector<int> build_fused_steps(const FusedSeg *seg, int nseg, int TH) {
             const St &nx = st[s + 1];
             d[2] |= (1 << 30) | (nx.seg << 24) | ((nx.cidx & 1) << 23) | nx.chunk;
         }
-        // in-place normalisation rounds of the next chunk at taps 1..NROUND of a 9-tap chunk
-        if (c.taps == 9 && c.tap >= 1 && c.tap <= NROUND && c.cidx + 1 < nchunks) {
+        // in-place normalisation rounds of the next chunk at taps 2..NROUND+1 of a 9-tap chunk
+        if (c.taps == 9 && c.tap >= 2 && c.tap <= NROUND + 1 && c.cidx + 1 < nchunks) {
             const St &nx = st[first[c.cidx + 1]];
             if (seg[nx.seg].ss_off >= 0)
-                d[3] = (int)(0x80000000u | (c.tap == 1 ? (1 << 30) : 0) | (nx.seg << 24) | ((nx.cidx & 1) << 23) |
-                             ((c.tap - 1) << 16) | nx.chunk);
+                d[3] = (int)(0x80000000u | (c.tap == 2 ? (1 << 30) : 0) | (nx.seg << 24) | ((nx.cidx & 1) << 23) |
+                             ((c.tap - 2) << 16) | nx.chunk);
         }
     }
     out[(size_t)n * 4 + 0] = st[0].kofs;
     out[(size_t)n * 4 + 1] = st[std::min(1, n - 1)].kofs;
+    out[(size_t)n * 4 + 2] = st[std::min(2, n - 1)].kofs;
     return out;
 }
 
@@ -592,6 +666,12 @@ int launch_conv_fused(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
                 case 4: return launch_fused_t<_Float16, 16, 4>(a, st);
                 case 8: return launch_fused_t<_Float16, 16, 8>(a, st);
                 case 7: return launch_fused_t<_Float16, 16, 7>(a, st);
+                case 14: return launch_fused_t<_Float16, 16, 14>(a, st);
+                case 11: return launch_fused_t<_Float16, 16, 11>(a, st);
+                case 13: return launch_fused_t<_Float16, 16, 13>(a, st);
+                case 10: return launch_fused_t<_Float16, 16, 10>(a, st);
+                case 16: return launch_fused_t<_Float16, 16, 16>(a, st);
+                case 24: return launch_fused_t<_Float16, 16, 24>(a, st);
                 case 15: return launch_fused_t<_Float16, 16, 15>(a, st);
                 default: break;
             }
@@ -603,18 +683,20 @@ int launch_conv_fused(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
 
 int launch_gn_small(int dtype, const void *x1, int C1, const void *x2, int C2, int B, int HW, int groups, float eps,
                     const float *gamma, const float *beta, int silu, void *out, hipStream_t st) {
-    const int C = C1 + C2, CH = C / 8;
-    if (C % 8 || C1 % 8 || CH > 512 || C % groups) {
-        set_error("gn_small: unsupported channels %d+%d", C1, C2);
+    const int C = C1 + C2;
+    // a block owns C/8 channels = 4 groups; chunks of 8 channels must not straddle x1 | x2
+    if (groups != 32 || C % 64 || C1 % 8 || C > 2048) {
+        set_error("gn_small: unsupported channels %d+%d (groups %d)", C1, C2, groups);
         return BNDM_E_ARG;
     }
-    const int RP = 512 / CH;
-    const size_t smem = (size_t)RP * C * 2 * 4 + (size_t)2 * C * 4;
+    const int Cb = C / 8, CHb = Cb / 8, RP = 256 / CHb;
+    const size_t smem = (size_t)RP * Cb * 2 * 4 + (size_t)2 * Cb * 4;
+    const dim3 grid(8, B);
     if (dtype == BNDM_DTYPE_F16)
-        hipLaunchKernelGGL(gn_small_kernel<_Float16>, dim3(B), dim3(512), smem, st, (const _Float16 *)x1, C1,
+        hipLaunchKernelGGL(gn_small_kernel<_Float16>, grid, dim3(256), smem, st, (const _Float16 *)x1, C1,
                            (const _Float16 *)x2, C2, HW, groups, eps, gamma, beta, silu, (_Float16 *)out);
     else
-        hipLaunchKernelGGL(gn_small_kernel<__bf16>, dim3(B), dim3(512), smem, st, (const __bf16 *)x1, C1,
+        hipLaunchKernelGGL(gn_small_kernel<__bf16>, grid, dim3(256), smem, st, (const __bf16 *)x1, C1,
                            (const __bf16 *)x2, C2, HW, groups, eps, gamma, beta, silu, (__bf16 *)out);
     return launch_status("gn_small");
 }
@@ -622,12 +704,12 @@ int launch_gn_small(int dtype, const void *x1, int C1, const void *x2, int C2, i
 int launch_gn_finalize2(const float *p1, int nslab1, int C1, const float *p2, int nslab2, int C2, int B, int HW,
                         int groups, float eps, const float *gamma, const float *beta, float *scale_shift,
                         hipStream_t st) {
-    if (C1 + C2 > 1024 || (C1 + C2) % groups) {
+    if (C1 + C2 > 2048 || groups != 32 || (C1 + C2) % 64) {
         set_error("gn_finalize2: C=%d groups=%d unsupported", C1 + C2, groups);
         return BNDM_E_ARG;
     }
-    hipLaunchKernelGGL(gn_finalize2_kernel, dim3(B), dim3(256), 0, st, p1, nslab1, C1, p2, nslab2, C2, HW, groups, eps,
-                       gamma, beta, scale_shift);
+    hipLaunchKernelGGL(gn_finalize2_kernel, dim3(8, B), dim3(128), 0, st, p1, nslab1, C1, p2, nslab2, C2, HW, groups,
+                       eps, gamma, beta, scale_shift);
     return launch_status("gn_finalize2");
 }
 

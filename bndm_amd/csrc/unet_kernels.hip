@@ -54,7 +54,10 @@ __device__ __forceinline__ void kiter_next(KIter &k, const ConvArgs &a) {
     }
 }
 
-template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int EPI, int STAGES>
+// FAST: no segment is upsampled -> per-step addressing comes from the host-built step table
+// (ConvArgs::steps: {segment | tap << 8, pixel delta dy*Ws+dx, channel offset, -}) plus a per-piece base
+// pixel and 9-bit tap-validity mask computed once; the generic path walks segments/taps in-kernel.
+template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int EPI, int STAGES, bool FAST>
 __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvArgs a, const int ksteps,
                                                                      const int logW, const int logH,
                                                                      const int ntm, const int ntn) {
@@ -114,6 +117,55 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
 #pragma unroll
     for (int i = 0; i < NWP; ++i)
         wsrc[i] = (const char *)a.Wgt + ((size_t)(n0 + prow + RPI * i) * a.Ktot + lchunk * 8) * 2;
+    // FAST path: centre-tap source pixel and tap-validity mask of every piece
+    int pbase[NXP], vmask[NXP];
+    if (FAST) {
+        const int Hs = H * a.stride, Ws = Wd * a.stride;
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {
+            const int cy = py[i] * a.stride, cx = px[i] * a.stride;
+            pbase[i] = (pb[i] * Hs + cy) * Ws + cx;
+            int vm = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                const bool ok = (unsigned)(cy + dy) < (unsigned)Hs && (unsigned)(cx + dx) < (unsigned)Ws && pb[i] >= 0;
+                vm |= ok ? (1 << t) : 0;
+            }
+            vmask[i] = vm;
+        }
+    }
+    const int4 *stab = reinterpret_cast<const int4 *>(a.steps);
+    auto seg_of = [&](int si) {
+        ConvSeg sg = a.seg[0];
+        if (si == 1) sg = a.seg[1];
+        if (si == 2) sg = a.seg[2];
+        if (si == 3) sg = a.seg[3];
+        return sg;
+    };
+    // the descriptor of the NEXT staged step is fetched while the current one is used, so the scalar load
+    // never sits right in front of an lgkmcnt wait
+    int4 dsc = FAST ? stab[min(ks_begin, ksteps - 1)] : int4{0, 0, 0, 0};
+    auto stage_fast = [&](int buf, int ks) {
+        char *base = smem + buf * STAGE;
+        const int kc = min(ks, ksteps - 1);
+        const int4 d = dsc;
+        dsc = stab[min(ks + 1, ksteps - 1)];
+        const ConvSeg sg = seg_of(d.x & 0xff);
+        const int tap = (d.x >> 8) & 0xf;
+        const char *sbase = (const char *)sg.src;
+        const int coff = d.z + lchunk * 8;
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {
+            const bool ok = (vmask[i] >> tap) & 1;
+            const long off = ((long)(pbase[i] + d.y) * sg.C + coff) * 2;
+            const char *src = ok ? sbase + off : (const char *)a.zeros;
+            glds16(src, base + i * (RPI * 128) + w * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < NWP; ++i)
+            glds16(wsrc[i] + (size_t)kc * 128, base + X_BYTES + i * (RPI * 128) + w * 1024);
+    };
 
     auto stage = [&](int buf, const KIter &k, int ks) {
         char *base = smem + buf * STAGE;
@@ -161,12 +213,17 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
     // after the issue of stage s+STAGES-2; one raw s_barrier per K-step both publishes stage s to all
     // waves and retires the buffer that the next issue overwrites.
     KIter kit;
-    kiter_init(kit, a, ks_begin);
+    if (!FAST) kiter_init(kit, a, ks_begin);
     int issued = 0;
 #pragma unroll
     for (int p = 0; p < STAGES - 1; ++p) {
-        stage(p, kit, ks_begin + (issued < nsteps ? issued : max(nsteps - 1, 0)));
-        if (issued + 1 < nsteps) kiter_next(kit, a);
+        const int ksi = ks_begin + (issued < nsteps ? issued : max(nsteps - 1, 0));
+        if (FAST) {
+            stage_fast(p, ksi);
+        } else {
+            stage(p, kit, ksi);
+            if (issued + 1 < nsteps) kiter_next(kit, a);
+        }
         ++issued;
     }
     int cur = 0, nxt = STAGES - 1;
@@ -175,8 +232,13 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         {
-            stage(nxt, kit, ks_begin + (issued < nsteps ? issued : nsteps - 1));
-            if (issued + 1 < nsteps) kiter_next(kit, a);
+            const int ksi = ks_begin + (issued < nsteps ? issued : nsteps - 1);
+            if (FAST) {
+                stage_fast(nxt, ksi);
+            } else {
+                stage(nxt, kit, ksi);
+                if (issued + 1 < nsteps) kiter_next(kit, a);
+            }
             ++issued;
         }
         const char *Xt = smem + cur * STAGE;
@@ -596,8 +658,8 @@ inline int ilog2(int v) {
     return r;
 }
 
-template <typename T, int WM, int WN, int TM, int TN, int EPI, int STAGES>
-int launch_conv_cfg(const ConvArgs &a, hipStream_t st) {
+template <typename T, int WM, int WN, int TM, int TN, int EPI, int STAGES, bool FAST>
+int launch_conv_cfg2(const ConvArgs &a, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int smem = STAGES * (BM + BN) * 128;
     int ksteps = 0;
@@ -607,14 +669,22 @@ int launch_conv_cfg(const ConvArgs &a, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
         BNDM_CHECK_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&conv_igemm<T, WM, WN, TM, TN, EPI, STAGES>),
+            reinterpret_cast<const void *>(&conv_igemm<T, WM, WN, TM, TN, EPI, STAGES, FAST>),
             hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr = true;
     }
     dim3 grid(ntm * ntn, a.splitk > 1 ? a.splitk : 1);
-    hipLaunchKernelGGL((conv_igemm<T, WM, WN, TM, TN, EPI, STAGES>), grid, dim3(WM * WN * 64), smem, st, a, ksteps,
-                       ilog2(a.W), ilog2(a.H), ntm, ntn);
+    hipLaunchKernelGGL((conv_igemm<T, WM, WN, TM, TN, EPI, STAGES, FAST>), grid, dim3(WM * WN * 64), smem, st, a,
+                       ksteps, ilog2(a.W), ilog2(a.H), ntm, ntn);
     return launch_status("conv_igemm");
+}
+
+template <typename T, int WM, int WN, int TM, int TN, int EPI, int STAGES>
+int launch_conv_cfg(const ConvArgs &a, hipStream_t st) {
+    bool fast = a.steps != nullptr;
+    for (int i = 0; i < a.nseg; ++i) fast = fast && !a.seg[i].up;
+    return fast ? launch_conv_cfg2<T, WM, WN, TM, TN, EPI, STAGES, true>(a, st)
+                : launch_conv_cfg2<T, WM, WN, TM, TN, EPI, STAGES, false>(a, st);
 }
 
 template <typename T>
@@ -681,6 +751,23 @@ int launch_conv_in(int dtype, const float *x, int Cx, const float *extra, int Ce
         hipLaunchKernelGGL(conv_in_kernel<__bf16>, dim3(blocks), dim3(256), smem, st, x, Cx, extra, Ce,
                            (const __bf16 *)W16, bias, (__bf16 *)out, stats, B, ilog2(H), ilog2(W), C0, KP);
     return launch_status("conv_in");
+}
+
+// Host: per-K-step table of the FAST addressing path (4 ints per step)
+std::vector<int> build_conv_steps(const ConvSeg *seg, int nseg, int W_out, int stride) {
+    std::vector<int> out;
+    const int Ws = W_out * stride;
+    for (int i = 0; i < nseg; ++i)
+        for (int t = 0; t < seg[i].taps; ++t)
+            for (int c = 0; c < seg[i].C / 64; ++c) {
+                const int tap = seg[i].taps == 9 ? t : 4;
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                out.push_back(i | (tap << 8));
+                out.push_back(dy * Ws + dx);
+                out.push_back(c * 64);
+                out.push_back(0);
+            }
+    return out;
 }
 
 int conv_tile_bm(int tile) { return tile == TILE_256x128 ? 256 : 128; }

@@ -34,6 +34,7 @@ struct ConvArgs {
     int Ktot;
     int splitk;          // >1: fp32 partial slabs [splitk][M][Cout] into `out`, no bias
     const void *zeros;   // >= 16 bytes of zeros (source of padding taps)
+    const void *steps;   // device copy of build_conv_steps(...) or nullptr (generic addressing)
 };
 
 enum ConvEpilogue { EPI_NHWC16 = 0, EPI_F32_ROWS = 1, EPI_NCHW32 = 2 };
@@ -41,6 +42,7 @@ enum ConvTile { TILE_128x128 = 0, TILE_128x32 = 1, TILE_256x128 = 2 };
 int conv_tile_bm(int tile);
 
 int launch_conv(int dtype, int tile, int epi, const ConvArgs &a, hipStream_t st);
+std::vector<int> build_conv_steps(const ConvSeg *seg, int nseg, int W_out, int stride);
 
 // sum split-K slabs + bias + temb + residual -> NHWC 16-bit
 int launch_splitk_reduce(int dtype, const float *part, int splitk, const ConvArgs &a, hipStream_t st);
