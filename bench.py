@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F16_TFLOPS = 2500.0       # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PMC_TRAFFIC_PER_LAUNCH = 99.0e6  # B, average over conv_fused launches (profiles/r01_pmc_traffic.txt)
 
 
 def cpu_baseline(nb_steps, seed=0):
@@ -165,10 +166,19 @@ def main():
         rc = lib.bndm_unet_profile(h, C.c_void_p(xs.data_ptr()), C.c_void_p(ts.data_ptr()), C.c_void_p(od.data_ptr()),
                                    B, 3, C.byref(prof), _lib.current_stream_ptr())
         _lib.check(rc, "bndm_unet_profile")
-        achieved = prof.conv_flops / (prof.ms_conv * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_igemm", "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
-                "launches_per_forward": prof.conv_launches, "ms_per_forward_conv": round(prof.ms_conv, 3),
+        achieved = prof.dom_flops / (prof.ms_dom * 1e-3) / 1e12
+        conv_all = prof.conv_flops / (prof.ms_conv * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv_fused<TH=16> (GroupNorm+SiLU fused 3x3 conv, 256-pixel tiles)",
+                "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_F16_TFLOPS, 4),
+                # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE
+                # doubled per MI355X_MICROARCH.md + WRITE_SIZE), see profiles/r01_pmc_traffic.txt
+                "traffic": PMC_TRAFFIC_PER_LAUNCH,
+                "launches_per_forward": prof.dom_launches,
+                "avg_launch_us": round(prof.ms_dom / max(prof.dom_launches, 1) * 1e3, 2),
+                "algorithmic_flop_per_launch": prof.dom_flops / max(prof.dom_launches, 1),
+                "algorithmic_bytes_per_launch": prof.dom_bytes / max(prof.dom_launches, 1),
+                "all_conv_kernels_tflops": round(conv_all, 1), "ms_per_forward_conv": round(prof.ms_conv, 3),
                 "ms_per_forward_total": round(prof.ms_total, 3), "launches_total": prof.launches}
 
     if rank == 0:

@@ -26,7 +26,8 @@ class UNetConfig(C.Structure):
 
 class UNetProfile(C.Structure):
     _fields_ = [("ms_total", C.c_float), ("ms_conv", C.c_float), ("conv_launches", C.c_int),
-                ("conv_flops", C.c_double), ("launches", C.c_int)]
+                ("conv_flops", C.c_double), ("launches", C.c_int), ("ms_dom", C.c_float),
+                ("dom_launches", C.c_int), ("dom_flops", C.c_double), ("dom_bytes", C.c_double)]
 
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t

@@ -77,6 +77,9 @@ struct Op {
     double flops_per_sample;   // algorithmic 2*MAC per batch element (convs only)
     std::function<int(RunCtx &)> run;
     std::string name;
+    bool dominant = false;          // conv_fused, 256-pixel tiles
+    double bytes_per_sample = 0;    // algorithmic HBM bytes per batch element (activations)
+    double bytes_fixed = 0;         // weights
 };
 
 }  // namespace
@@ -399,7 +402,7 @@ struct Builder {
         a.zeros = h->zeros;
         const int TH = out.H >= 32 ? 16 : 8;
         {
-            const std::vector<int> tab = build_fused_steps(a.seg, a.nseg, TH);
+            const std::vector<int> tab = build_fused_steps(a.seg, a.nseg, TH, conv_fused_threads(TH));
             void *dtab;
             if ((rc = upload(h, tab.data(), tab.size() * sizeof(int), &dtab))) return;
             a.steps = dtab;
@@ -409,6 +412,10 @@ struct Builder {
         if (want_stats) pst = new_stats(out, conv_fused_tiles_per_sample(TH, out.H, out.W)).pslot;
         else stats_of.erase(out.slot);
         cur_name = S("cnvF %-44s K=%-5d N=%-4d %dx%d", label.c_str(), Ktot, out.C, out.H, out.W);
+        double abytes = 2.0 * out.C * out.H * out.W * (resid ? 2 : 1);
+        for (const FIn &f : ins) abytes += 2.0 * f.a.C * f.a.H * f.a.W;
+        const double wbytes = 2.0 * Ktot * out.C;
+        const size_t op_index = h->ops.size();
         push(OPC_CONV, 2.0 * mac * out.C * out.H * out.W, [=](RunCtx &r) {
             FusedArgs c = a;
             for (int i = 0; i < c.nseg; ++i) c.seg[i].src = hh->P(slots[i]);
@@ -421,6 +428,9 @@ struct Builder {
             c.stats = pst >= 0 ? (float *)hh->P(pst) : nullptr;
             return launch_conv_fused(hh->dtype(), TH, c, r.st);
         });
+        h->ops[op_index].dominant = TH == 16;
+        h->ops[op_index].bytes_per_sample = abytes;
+        h->ops[op_index].bytes_fixed = wbytes;
     }
 
     struct SegIn {
@@ -1139,6 +1149,19 @@ extern "C" int bndm_unet_profile(bndm_unet *h, const float *sample, const float 
             conv_flops += h->ops[k].flops_per_sample * B;
             ++conv_launches;
         }
+    double dom_ms = 0, dom_flops = 0, dom_bytes = 0;
+    int dom_n = 0;
+    for (size_t k = 0; k < nops; ++k)
+        if (h->ops[k].dominant) {
+            dom_ms += op_ms[k] / iters;
+            dom_flops += h->ops[k].flops_per_sample * B;
+            dom_bytes += h->ops[k].bytes_per_sample * B + h->ops[k].bytes_fixed;
+            ++dom_n;
+        }
+    prof->ms_dom = (float)dom_ms;
+    prof->dom_launches = dom_n;
+    prof->dom_flops = dom_flops;
+    prof->dom_bytes = dom_bytes;
     prof->ms_conv = (float)(conv_ms / iters);
     prof->conv_flops = conv_flops;
     prof->conv_launches = conv_launches;

@@ -34,8 +34,9 @@ struct StepDesc {
 
 // ABL: ablation switches for profiling only (results are wrong when non-zero):
 //   1 skip the MFMAs, 2 skip in-loop weight DMA, 4 skip in-loop LDS fragment reads, 8 skip in-loop patch work
-template <typename T, int TH, int ABL>
-__global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepDesc *__restrict__ steps,
+// NW: waves per block (8: 64x64 wave tiles, 2 waves per SIMD; 16: 32x64 wave tiles, 4 waves per SIMD)
+template <typename T, int TH, int ABL, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_fused(const FusedArgs a, const StepDesc *__restrict__ steps,
                                                   const int tiles_x, const int tps, const int ntn,
                                                   const int nsteps) {
     using v8 = typename TT<T>::v8;
@@ -43,11 +44,15 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
     constexpr int TW = 16, PW = TW + 2, PH = TH + 2;
     constexpr int NPP = PH * PW;                       // patch pixels
     constexpr int NPIECE = NPP * 8;                    // 16-byte pieces per patch chunk
-    constexpr int NROUND = (NPIECE + 511) / 512;       // patch DMA rounds per chunk (the last one is partial)
-    constexpr int NREMW = (NPIECE - (NROUND - 1) * 512 + 63) / 64;   // waves that take part in the last round
-    constexpr int PATCH_BYTES = (NROUND - 1) * 8192 + NREMW * 1024;
+    constexpr int NT = NW * 64;                        // threads per block
+    constexpr int NROUND = (NPIECE + NT - 1) / NT;     // patch DMA rounds per chunk (the last one is partial)
+    constexpr int NREMW = (NPIECE - (NROUND - 1) * NT + 63) / 64;    // waves that take part in the last round
+    constexpr int PATCH_BYTES = (NROUND - 1) * NT * 16 + NREMW * 1024;
+    constexpr int WAVES_M = NW / 2;                    // waves along M (2 along N)
+    constexpr int NWP = 1024 / NT;                     // weight-tile DMAs per thread per K-step
     constexpr int BM = TH * TW;
-    constexpr int TM = TH / 8;                         // 32-pixel MFMA tiles per wave along M
+    constexpr int TM = (TH * TW) / (WAVES_M * 32);     // 32-pixel MFMA tiles per wave along M
+    static_assert(TM >= 1 && (TH % WAVES_M) == 0 && (TH / WAVES_M) % 2 == 0, "wave tiling");
     constexpr int TN = 2;
     constexpr int WSTAGES = 4;
     constexpr int W_BYTES = 128 * 128;
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
     float *ssL = reinterpret_cast<float *>(smem + OFF_SS);
     if (a.ss) {
         const float *g = a.ss + (size_t)b * 2 * a.ssC;
-        for (int i = tid; i < 2 * a.ssC; i += 512) ssL[i] = g[i];
+        for (int i = tid; i < 2 * a.ssC; i += NT) ssL[i] = g[i];
     }
 
     // ---- patch piece descriptors (independent of the chunk) ----------------------------------------
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
     int p_valid = 0;                                   // bit r: piece of round r is inside the image
 #pragma unroll
     for (int r = 0; r < NROUND; ++r) {
-        const int piece = r * 512 + tid;
+        const int piece = r * NT + tid;
         const int pc = piece < NPIECE ? piece : NPIECE - 1;
         const int pp = pc >> 3, pch = pc & 7;
         const int pyy = pp / PW, pxx = pp - pyy * PW;
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
             const int pix = sg.up ? p_half[r] : p_full[r];
             const char *src = pix >= 0 ? sbase + ((size_t)pix * sg.C + chunk * 64 + p_lc[r] * 8) * 2
                                        : (const char *)a.zeros;
-            glds16(src, P + r * 8192 + w * 1024);
+            glds16(src, P + r * (NT * 16) + w * 1024);
         }
     };
     const bool last_round_wave = w < NREMW;            // wave-uniform
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
     auto xf_load = [&](int xd, XfRegs &x) {
         const int round = (xd >> 16) & 7, chunk = xd & 0xffff, buf = (xd >> 23) & 1;
         const int ss_off = seg_of((xd >> 24) & 3).ss_off;
-        const int piece = round * 512 + tid;
+        const int piece = round * NT + tid;
         const int lc = (piece & 7) ^ ((piece >> 4) & 7);                 // pch ^ ((pp >> 1) & 7), pp = piece >> 3
         x.addr = smem + buf * PATCH_BYTES + piece * 16;
         x.valid = (p_valid >> round) & 1;
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
     auto w_issue = [&](int buf, int kofs) {
         char *base = smem + OFF_W + buf * W_BYTES;
         glds16(wsrc0 + (size_t)kofs * 2, base + w * 1024);
-        glds16(wsrc1 + (size_t)kofs * 2, base + 8192 + w * 1024);
+        if (NWP == 2) glds16(wsrc1 + (size_t)kofs * 2, base + 8192 + w * 1024);
     };
 
     f32x16 acc[TN][TM];
@@ -180,9 +185,9 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int wm = w & 3, wn = w >> 2;
+    const int wm = w % WAVES_M, wn = w / WAVES_M;
     const int q = l & 31, kh = l >> 5, wkey = (l >> 1) & 7;
-    const int row_base = wm * (TH / 4);
+    const int row_base = wm * (TH / WAVES_M);
     const int lr = q >> 4, lcx = q & 15;
 
     // ---- ping-pong schedule ------------------------------------------------------------------------
@@ -231,14 +236,14 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
             }
             return;
         }
-        __builtin_amdgcn_s_setprio(1);
+        if (!(ABL & 32)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int j = 0; j < TM; ++j) acc[i][j] = TT<T>::mfma(fa[ks][i], fb[ks][j], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
+        if (!(ABL & 32)) __builtin_amdgcn_s_setprio(0);
     };
     // DMA work of the even phase of a step (returns true if a slack patch DMA followed the weight DMA)
     // returns 0: only the weight tile, 1: a slack patch DMA followed it, 2: a late 1x1 patch DMA preceded it
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
     w_issue(0, steps[nsteps].x);                        // the table's extra entry carries the k-offsets of steps 0..2
     w_issue(1, steps[nsteps].y);
     w_issue(2, steps[nsteps].z);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // own patch pieces landed (weights may still fly)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NWP) : "memory");    // own patch pieces landed (weights may still fly)
     __syncthreads();                                   // ss table visible (written above by plain stores)
     if (a.seg[0].ss_off >= 0) {
         for (int r = 0; r < NROUND; ++r) {
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
             xf_math_store(x);
         }
     }
-    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NWP) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
             const StepDesc dn2 = steps[s + 2 < nsteps ? s + 2 : nsteps - 1];
             // (rounds start two taps after the patch DMA: only one younger weight tile is in flight then)
             const bool dox = !(ABL & 8) && dcur.w < 0 && (last_round_wave || ((dcur.w >> 16) & 7) != NROUND - 1);
-            if (!(ABL & 16) && dox && (dcur.w & (1 << 30))) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // patch DMA landed
+            if (!(ABL & 16) && dox && (dcur.w & (1 << 30))) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWP) : "memory");   // patch DMA landed
             const int issued = even_dma(dcur, wnext);
             if (dox) {
                 // normalisation arithmetic rides in the shadow of the matrix pipe
@@ -323,10 +328,10 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
             }
             // weight tile s+1 landed: WSTAGES-2 younger tiles (+ a patch DMA issued after them) may still fly
             if (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // profiling: never wait for DMA
-            else if (issued == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (WSTAGES - 2)) : "memory");
-            else if (issued == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");   // late patch: only the newest tile may fly
-            else if (last_round_wave) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (WSTAGES - 2) + NROUND) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (WSTAGES - 2) + NROUND - 1) : "memory");
+            else if (issued == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NWP * (WSTAGES - 2)) : "memory");
+            else if (issued == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NWP) : "memory");   // late patch: only the newest tile may fly
+            else if (last_round_wave) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NWP * (WSTAGES - 2) + NROUND) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NWP * (WSTAGES - 2) + NROUND - 1) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const int wn1 = wcur + 1 == WSTAGES ? 0 : wcur + 1;
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
             asm volatile("" ::: "memory");
             const StepDesc dn2 = steps[s + 2 < nsteps ? s + 2 : nsteps - 1];
             const bool dox = !(ABL & 8) && dcur.w < 0 && (last_round_wave || ((dcur.w >> 16) & 7) != NROUND - 1);
-            if (!(ABL & 16) && dox && (dcur.w & (1 << 30))) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (!(ABL & 16) && dox && (dcur.w & (1 << 30))) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWP) : "memory");
             const int issued = even_dma(dcur, wnext);
             if (dox) {
                 // fragment reads first, normalisation arithmetic while they are in flight
@@ -356,10 +361,10 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
             }
             // weight tile s+1 landed: WSTAGES-2 younger tiles (+ a patch DMA issued after them) may still fly
             if (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // profiling: never wait for DMA
-            else if (issued == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (WSTAGES - 2)) : "memory");
-            else if (issued == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");   // late patch: only the newest tile may fly
-            else if (last_round_wave) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (WSTAGES - 2) + NROUND) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (WSTAGES - 2) + NROUND - 1) : "memory");
+            else if (issued == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NWP * (WSTAGES - 2)) : "memory");
+            else if (issued == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NWP) : "memory");   // late patch: only the newest tile may fly
+            else if (last_round_wave) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NWP * (WSTAGES - 2) + NROUND) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NWP * (WSTAGES - 2) + NROUND - 1) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             multiply();
@@ -413,13 +418,14 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
     __syncthreads();
 
     // ---- epilogue 2: full-row stores + per-channel statistics of the stored values -------------------
+    constexpr int RPE = NT / 16;                         // pixel rows handled per pass
     const int c16 = tid & 15, prw = tid >> 4;            // 16-byte chunk (8 channels), pixel row slot
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
 #pragma unroll
-    for (int i = 0; i < BM / 32; ++i) {
-        const int pl = prw + 32 * i;
+    for (int i = 0; i < BM / RPE; ++i) {
+        const int pl = prw + RPE * i;
         const v8 v = *reinterpret_cast<const v8 *>(stg + pl * 256 + ((c16 ^ (pl & 15)) << 4));
         const size_t m = (size_t)(b * H + y0 + (pl >> 4)) * Wd + x0 + (pl & 15);
         *reinterpret_cast<v8 *>((T *)a.out + m * a.Cout + n0 + c16 * 8) = v;
@@ -441,22 +447,23 @@ __global__ __launch_bounds__(512) void conv_fused(const FusedArgs a, const StepD
         if (tid < 256) {
             const int ch = tid >> 1, which = tid & 1;
             float t = 0.f;
-            for (int r = 0; r < 32; ++r) t += red[((r * 128) + ch) * 2 + which];
+            for (int r = 0; r < RPE; ++r) t += red[((r * 128) + ch) * 2 + which];
             a.stats[((size_t)(b * tps + tin) * a.Cout + n0 + ch) * 2 + which] = t;
         }
     }
 }
 
-template <typename T, int TH, int ABL>
+template <typename T, int TH, int ABL, int NW = 8>
 int launch_fused_t(const FusedArgs &a, hipStream_t st) {
-    constexpr int NPIECE = (TH + 2) * 18 * 8, NROUND = (NPIECE + 511) / 512;
-    constexpr int PATCH_BYTES = (NROUND - 1) * 8192 + ((NPIECE - (NROUND - 1) * 512 + 63) / 64) * 1024;
+    constexpr int NT = NW * 64;
+    constexpr int NPIECE = (TH + 2) * 18 * 8, NROUND = (NPIECE + NT - 1) / NT;
+    constexpr int PATCH_BYTES = (NROUND - 1) * NT * 16 + ((NPIECE - (NROUND - 1) * NT + 63) / 64) * 1024;
     constexpr int main_bytes = 2 * PATCH_BYTES + 4 * 16384 + 8192;
-    constexpr int epi_bytes = TH * 16 * 256 + 32 * 128 * 2 * 4;
+    constexpr int epi_bytes = TH * 16 * 256 + (NT / 16) * 128 * 2 * 4;
     constexpr int smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
     static bool attr = false;
     if (!attr) {
-        BNDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_fused<T, TH, ABL>),
+        BNDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_fused<T, TH, ABL, NW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr = true;
     }
@@ -464,7 +471,7 @@ int launch_fused_t(const FusedArgs &a, hipStream_t st) {
     int nsteps = 0;
     for (int i = 0; i < a.nseg; ++i) nsteps += a.seg[i].taps * (a.seg[i].C / 64);
     dim3 grid(a.B * tps * ntn);
-    hipLaunchKernelGGL((conv_fused<T, TH, ABL>), grid, dim3(512), smem, st, a, (const StepDesc *)a.steps, tiles_x, tps,
+    hipLaunchKernelGGL((conv_fused<T, TH, ABL, NW>), grid, dim3(NT), smem, st, a, (const StepDesc *)a.steps, tiles_x, tps,
                        ntn, nsteps);
     return launch_status("conv_fused");
 }
@@ -589,9 +596,9 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const T *__restrict__ x1,
 
 // Host: the per-step schedule of conv_fused for a segment list (see StepDesc).  Returns nsteps + 1
 // entries; the extra last entry carries the weight k-offsets of steps 0 and 1 for the prologue.
-std::vector<int> build_fused_steps(const FusedSeg *seg, int nseg, int TH) {
+std::vector<int> build_fused_steps(const FusedSeg *seg, int nseg, int TH, int nthreads) {
     const int PW = 18;
-    const int NROUND = ((TH + 2) * 18 * 8 + 511) / 512;
+    const int NROUND = ((TH + 2) * 18 * 8 + nthreads - 1) / nthreads;
     struct St { int seg, chunk, tap, taps, cidx, kofs; };
     std::vector<St> st;
     int koff = 0, cidx = 0;
@@ -637,6 +644,12 @@ std::vector<int> build_fused_steps(const FusedSeg *seg, int nseg, int TH) {
 
 int conv_fused_tiles_per_sample(int TH, int H, int W) { return (H / TH) * (W / 16); }
 
+// threads per block of the variant used for tile height TH (BNDM_FUSED_NW=8|16 overrides the default)
+int conv_fused_threads(int TH) {
+    static const int nw = getenv("BNDM_FUSED_NW") ? atoi(getenv("BNDM_FUSED_NW")) : 8;
+    return (TH == 16 && nw == 16) ? 1024 : 512;
+}
+
 int launch_conv_fused(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
     if ((TH != 8 && TH != 16) || a.H % TH || a.W % 16 || a.Cout % 128 || a.nseg < 1 || a.nseg > CONV_MAX_SEG) {
         set_error("launch_conv_fused: unsupported shape TH=%d H=%d W=%d Cout=%d nseg=%d", TH, a.H, a.W, a.Cout,
@@ -671,13 +684,16 @@ int launch_conv_fused(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
                 case 13: return launch_fused_t<_Float16, 16, 13>(a, st);
                 case 10: return launch_fused_t<_Float16, 16, 10>(a, st);
                 case 16: return launch_fused_t<_Float16, 16, 16>(a, st);
+                case 32: return launch_fused_t<_Float16, 16, 32>(a, st);
                 case 24: return launch_fused_t<_Float16, 16, 24>(a, st);
                 case 15: return launch_fused_t<_Float16, 16, 15>(a, st);
                 default: break;
             }
         }
+        if (TH == 16 && conv_fused_threads(16) == 1024) return launch_fused_t<_Float16, 16, 0, 16>(a, st);
         return TH == 16 ? launch_fused_t<_Float16, 16, 0>(a, st) : launch_fused_t<_Float16, 8, 0>(a, st);
     }
+    if (TH == 16 && conv_fused_threads(16) == 1024) return launch_fused_t<__bf16, 16, 0, 16>(a, st);
     return TH == 16 ? launch_fused_t<__bf16, 16, 0>(a, st) : launch_fused_t<__bf16, 8, 0>(a, st);
 }
 

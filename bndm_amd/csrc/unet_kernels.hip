@@ -681,7 +681,10 @@ int launch_conv_cfg2(const ConvArgs &a, hipStream_t st) {
 
 template <typename T, int WM, int WN, int TM, int TN, int EPI, int STAGES>
 int launch_conv_cfg(const ConvArgs &a, hipStream_t st) {
-    bool fast = a.steps != nullptr;
+    // the table-driven path pays ~100 VALU of per-piece set-up: only worth it with enough K-steps per block
+    int ksteps = 0;
+    for (int i = 0; i < a.nseg; ++i) ksteps += a.seg[i].taps * (a.seg[i].C / 64);
+    bool fast = a.steps != nullptr && ksteps / (a.splitk > 1 ? a.splitk : 1) >= 12;
     for (int i = 0; i < a.nseg; ++i) fast = fast && !a.seg[i].up;
     return fast ? launch_conv_cfg2<T, WM, WN, TM, TN, EPI, STAGES, true>(a, st)
                 : launch_conv_cfg2<T, WM, WN, TM, TN, EPI, STAGES, false>(a, st);

@@ -115,7 +115,8 @@ struct FusedArgs {
 int launch_conv_fused(int dtype, int TH, const FusedArgs &a, hipStream_t st);
 int conv_fused_tiles_per_sample(int TH, int H, int W);
 // per-step schedule table of conv_fused (host side; upload and pass as FusedArgs::steps)
-std::vector<int> build_fused_steps(const FusedSeg *seg, int nseg, int TH);
+std::vector<int> build_fused_steps(const FusedSeg *seg, int nseg, int TH, int nthreads);
+int conv_fused_threads(int TH);
 
 // one-launch GroupNorm(+SiLU) for small per-sample tensors (statistics + apply, one block per sample)
 int launch_gn_small(int dtype, const void *x1, int C1, const void *x2, int C2, int B, int HW, int groups, float eps,
