@@ -98,6 +98,7 @@ struct bndm_unet {
     std::vector<Op> ops;
     int ntemb = 0;                     // total time_emb_proj columns
     void *zeros = nullptr;
+    unsigned *tile_counters = nullptr;   // split-K arrival counters (zeroed once; last arrivers reset them)
     // per-schedule time-embedding table (K10): [cap][ntemb] fp32, [cap] fp32 t, [cap][temb_dim] 16-bit
     float *tp_table = nullptr, *t_steps = nullptr;
     void *act_steps = nullptr;
@@ -517,6 +518,13 @@ struct Builder {
                 c.out = hh->P(so);
                 return launch_conv(hh->dtype(), tile, EPI_NHWC16, c, r.st);
             }
+            if (tile == TILE_128x128 && hh->tile_counters && nblk <= 4096) {
+                c.splitk = splitk;
+                c.out = hh->P(so);
+                c.part = (float *)hh->P(hh->s_splitk);
+                c.counters = hh->tile_counters;
+                return launch_conv(hh->dtype(), tile, EPI_SPLITK_FUSED, c, r.st);
+            }
             ConvArgs p = c;
             p.splitk = splitk;
             p.out = hh->P(hh->s_splitk);
@@ -705,6 +713,12 @@ struct Builder {
             std::vector<char> zz(256, 0);
             if ((rc = upload(h, zz.data(), zz.size(), &z))) return rc;
             h->zeros = z;
+            if (getenv("BNDM_FUSED_SPLITK")) {   // opt-in: in-launch reduction loses to a reduce launch at these slab sizes
+                std::vector<unsigned> cz(4096, 0u);
+                void *cnt;
+                if ((rc = upload(h, cz.data(), cz.size() * 4, &cnt))) return rc;
+                h->tile_counters = (unsigned *)cnt;
+            }
         }
 
         // ---- time embedding MLP (fp32, transposed weights for coalesced reads) ----------------------

@@ -208,35 +208,38 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
     const int frow = l & 31, kh = l >> 5, key = (l >> 1) & 7;
 
     // ---- STAGES-deep ring: stages s+1 .. s+STAGES-1 are in flight while step s is multiplied.
-    // Every thread issues exactly NLD loads per stage (empty tail stages re-read the last tile into
-    // a buffer nobody will read), so "stage s has landed" is the counted wait vmcnt(NLD*(STAGES-2))
-    // after the issue of stage s+STAGES-2; one raw s_barrier per K-step both publishes stage s to all
-    // waves and retires the buffer that the next issue overwrites.
+    // Every thread issues exactly NLD loads per stage, so "stage s has landed" is a counted wait on the
+    // stages issued after it; near the end of the K range fewer stages are in flight and the count
+    // shrinks accordingly (no dummy stages are issued).  One raw s_barrier per K-step both publishes
+    // stage s to all waves and retires the buffer that the next issue overwrites.
     KIter kit;
     if (!FAST) kiter_init(kit, a, ks_begin);
     int issued = 0;
 #pragma unroll
     for (int p = 0; p < STAGES - 1; ++p) {
-        const int ksi = ks_begin + (issued < nsteps ? issued : max(nsteps - 1, 0));
-        if (FAST) {
-            stage_fast(p, ksi);
-        } else {
-            stage(p, kit, ksi);
-            if (issued + 1 < nsteps) kiter_next(kit, a);
+        if (issued < nsteps) {
+            if (FAST) {
+                stage_fast(p, ks_begin + issued);
+            } else {
+                stage(p, kit, ks_begin + issued);
+                if (issued + 1 < nsteps) kiter_next(kit, a);
+            }
+            ++issued;
         }
-        ++issued;
     }
     int cur = 0, nxt = STAGES - 1;
     for (int it = 0; it < nsteps; ++it) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (STAGES - 2)) : "memory");
+        const int younger = issued - it - 1;           // stages in flight behind the one needed now (uniform)
+        if (younger >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (STAGES - 2)) : "memory");
+        else if (STAGES > 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        {
-            const int ksi = ks_begin + (issued < nsteps ? issued : nsteps - 1);
+        if (issued < nsteps) {
             if (FAST) {
-                stage_fast(nxt, ksi);
+                stage_fast(nxt, ks_begin + issued);
             } else {
-                stage(nxt, kit, ksi);
+                stage(nxt, kit, ks_begin + issued);
                 if (issued + 1 < nsteps) kiter_next(kit, a);
             }
             ++issued;
@@ -261,7 +264,6 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
         cur = cur + 1 == STAGES ? 0 : cur + 1;
         nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dummy tail stages before exit
 
     // ---- epilogue: lane owns pixel (l&31) of each M-tile and channels 8g + 4*kh + {0..3} -----------
     const int HW = 1 << (logW + logH);
@@ -301,7 +303,11 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
                         for (int e = 0; e < 4; ++e) v[e] += tv[e];
                     }
                 }
-                if (EPI == EPI_F32_ROWS) {
+                if (EPI == EPI_SPLITK_FUSED) {
+                    float *o = a.part + (size_t)blockIdx.y * M * a.Cout;
+                    f32x4 ov = {v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4 *>(o + (size_t)m * a.Cout + co) = ov;
+                } else if (EPI == EPI_F32_ROWS) {
                     float *o = (float *)a.out + (a.splitk > 1 ? (size_t)blockIdx.y * M * a.Cout : 0);
                     f32x4 ov = {v[0], v[1], v[2], v[3]};
                     *reinterpret_cast<f32x4 *>(o + (size_t)m * a.Cout + co) = ov;
@@ -318,6 +324,51 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
                     *reinterpret_cast<v4 *>((T *)a.out + (size_t)m * a.Cout + co) = ov;
                 }
             }
+        }
+    }
+
+    if (EPI == EPI_SPLITK_FUSED) {
+        // ---- in-launch split-K reduction (agent-scope release / acquire, placement independent) -----------
+        // every wave: slab stores retired; then ONE lane publishes with a release fence and takes a ticket
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int *flag = reinterpret_cast<int *>(smem);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned t = __hip_atomic_fetch_add(a.counters + tix, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = (t == (unsigned)a.splitk - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (*flag == 0) return;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(a.counters + tix, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        __syncthreads();
+        using v4 = typename TT<T>::v4;
+        constexpr int C4 = BN / 4;
+        for (int idx = tid; idx < BM * C4; idx += NT) {
+            const int row = idx / C4, c4 = idx - row * C4;
+            const int m = m0 + row, co = n0 + c4 * 4;
+            if (m >= M || co >= a.Cout) continue;
+            f32x4 sum = *reinterpret_cast<const f32x4 *>(a.part + (size_t)m * a.Cout + co);
+            for (int z = 1; z < a.splitk; ++z)
+                sum += *reinterpret_cast<const f32x4 *>(a.part + ((size_t)z * M + m) * a.Cout + co);
+            if (a.bias) sum += *reinterpret_cast<const f32x4 *>(a.bias + co);
+            if (a.temb) {
+                const int bb = m >> (logW + logH);
+                sum += *reinterpret_cast<const f32x4 *>(a.temb + (size_t)bb * a.temb_bstride + a.temb_off + co);
+            }
+            if (a.resid) {
+                const v4 rv = *reinterpret_cast<const v4 *>((const T *)a.resid + (size_t)m * a.Cout + co);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum[e] += (float)rv[e];
+            }
+            v4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = (T)sum[e];
+            *reinterpret_cast<v4 *>((T *)a.out + (size_t)m * a.Cout + co) = ov;
         }
     }
 }
@@ -366,35 +417,52 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float *__restrict__ 
                                                       T *__restrict__ out, float *__restrict__ stats, int B,
                                                       int logH, int logW, int C0, int KP) {
     // block = 128 consecutive pixels of one sample (H*W is a multiple of 128); wave = 32 pixels.
-    // The tile is staged in LDS so that rows are stored 16 B per lane and the per-channel sums for the
-    // first GroupNorm come out of the same pass.
+    // The fp32 NCHW input rows the block touches (its rows +-1, zero padded) are first copied to LDS as
+    // 16-bit with coalesced loads; every lane then builds its MFMA operand (27..54 taps) from LDS.
+    // The output tile is staged in LDS too: rows are stored 16 B per lane and the per-channel sums for
+    // the first GroupNorm come out of the same pass.
     using v8 = typename TT<T>::v8;
     using v4 = typename TT<T>::v4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
     const int H = 1 << logH, Wd = 1 << logW, HW = H * Wd;
     const int m0 = blockIdx.x * 128;
-    const int m = m0 + wv * 32 + (l & 31);
-    const int kh = l >> 5;
+    const int b = m0 >> (logW + logH);
     const int Cin = Cx + Ce;
-    const int xx = m & (Wd - 1), yy = (m >> logW) & (H - 1), b = m >> (logW + logH);
+    const int kh = l >> 5;
+    // ---- input patch: rows [ya-1, yb+1] x cols [xa-1, xb+1] of every input channel ----------------------
+    const int p0 = m0 & (HW - 1);
+    const int ya = p0 >> logW, yb = (p0 + 127) >> logW;                 // first / last image row of the block
+    const int xa = Wd >= 128 ? (p0 & (Wd - 1)) : 0;                     // a block is part of one row when W >= 128
+    const int pw = (Wd >= 128 ? 128 : Wd) + 2, ph = yb - ya + 3;
+    T *patch = reinterpret_cast<T *>(smem);                             // [Cin][ph][pw]
+    for (int i = tid; i < Cin * ph * pw; i += 256) {
+        const int px_ = i % pw, t = i / pw, py_ = t % ph, ci = t / ph;
+        const int iy = ya - 1 + py_, ix = xa - 1 + px_;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)Wd)
+            v = ci < Cx ? x[((size_t)b * Cx + ci) * HW + iy * Wd + ix]
+                        : extra[((size_t)b * Ce + (ci - Cx)) * HW + iy * Wd + ix];
+        patch[i] = (T)v;
+    }
+    __syncthreads();
+    const int m = m0 + wv * 32 + (l & 31);
+    const int xx = m & (Wd - 1), yy = (m >> logW) & (H - 1);
     const int nks = KP >> 4;
     v8 bf[4];
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 16 * s + 8 * kh + j;
-            float v = 0.f;
+            T v = (T)0.f;
             if (s < nks && k < 9 * Cin) {
-                const int ci = k / 9, t = k - ci * 9, dy = t / 3 - 1, dx = t - (dy + 1) * 3 - 1;
-                const int iy = yy + dy, ix = xx + dx;
-                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)Wd)
-                    v = ci < Cx ? x[((size_t)b * Cx + ci) * HW + iy * Wd + ix]
-                                : extra[((size_t)b * Ce + (ci - Cx)) * HW + iy * Wd + ix];
+                const int ci = k / 9, t = k - ci * 9, dy = t / 3, dx = t - dy * 3;      // dy, dx in 0..2
+                v = patch[(ci * ph + (yy - ya + dy)) * pw + (xx - xa + dx)];
             }
-            bf[s][j] = (T)v;
+            bf[s][j] = v;
         }
     }
+    __syncthreads();                                                   // patch is dead: the tile is staged over it
     const int rowB = C0 * 2;                       // bytes per staged pixel row
     const int pl = wv * 32 + (l & 31);             // pixel inside the block
     for (int n0 = 0; n0 < C0; n0 += 32) {
@@ -698,6 +766,7 @@ int launch_conv_t(int tile, int epi, const ConvArgs &a, hipStream_t st) {
     } else if (tile == TILE_128x128) {   // 4 waves, 4-stage ring (128 KB LDS)
         if (epi == EPI_NHWC16) return launch_conv_cfg<T, 2, 2, 2, 2, EPI_NHWC16, 4>(a, st);
         if (epi == EPI_F32_ROWS) return launch_conv_cfg<T, 2, 2, 2, 2, EPI_F32_ROWS, 4>(a, st);
+        if (epi == EPI_SPLITK_FUSED) return launch_conv_cfg<T, 2, 2, 2, 2, EPI_SPLITK_FUSED, 4>(a, st);
     } else if (tile == TILE_128x32) {    // 4 waves, 4-stage ring (80 KB LDS)
         if (epi == EPI_NCHW32) return launch_conv_cfg<T, 4, 1, 1, 1, EPI_NCHW32, 4>(a, st);
         if (epi == EPI_NHWC16) return launch_conv_cfg<T, 4, 1, 1, 1, EPI_NHWC16, 4>(a, st);
@@ -746,7 +815,10 @@ int launch_conv_in(int dtype, const float *x, int Cx, const float *extra, int Ce
         return BNDM_E_ARG;
     }
     const int blocks = M / 128;
-    const int smem = 128 * C0 * 2 + (256 / (C0 / 8)) * C0 * 2 * 4;
+    const int rows = (W >= 128 ? 1 : 128 / W) + 2, cols = (W >= 128 ? 128 : W) + 2;
+    const int patch_bytes = (Cx + Ce) * rows * cols * 2;
+    const int tile_bytes = 128 * C0 * 2 + (256 / (C0 / 8)) * C0 * 2 * 4;
+    const int smem = patch_bytes > tile_bytes ? patch_bytes : tile_bytes;
     if (dtype == BNDM_DTYPE_F16)
         hipLaunchKernelGGL(conv_in_kernel<_Float16>, dim3(blocks), dim3(256), smem, st, x, Cx, extra, Ce,
                            (const _Float16 *)W16, bias, (_Float16 *)out, stats, B, ilog2(H), ilog2(W), C0, KP);

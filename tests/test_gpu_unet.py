@@ -131,3 +131,19 @@ def test_ddim_loop_with_engine_matches_oracle_loop():
         ref = S.ddim_step(eps, int(t), ref, acp, ratio)
         got = sch.step(m(got, int(t)).sample, int(t), got).prev_sample
     assert _rel(got.cpu(), ref) <= 3e-3
+
+
+def test_conditional_superres_loop_matches_oracle():
+    """sample_iadb_conditional (iadb_bn.py:384-438): 6-channel input = cat(x, x_c), res 128."""
+    from oracle import sampler_oracle as S
+    from bndm_amd.sampler import sample_iadb_conditional
+    m, U, cfg, sd = _model_and_oracle(128, 6, 6)
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.randn(1, 3, 128, 128, generator=g)
+    x_c = torch.randn(1, 3, 128, 128, generator=g) * 0.5
+    params = torch.tensor([0.2, 0.0, 3.0])
+    ref, ref_snaps = S.sample_iadb(U.OracleUNet(cfg, sd), x0, 4, "sigmoid", params, 6, "gaussianBN", "test",
+                                   log_freq=25, x_c=x_c)
+    got, snaps = sample_iadb_conditional(m, x0.cuda(), x_c.cuda(), 4, "sigmoid", params.cuda(), 6, "gaussianBN", "test")
+    assert len(snaps) == len(ref_snaps)
+    assert _rel(got.cpu(), ref) <= 2e-3
