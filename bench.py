@@ -181,6 +181,34 @@ def main():
                 "all_conv_kernels_tflops": round(conv_all, 1), "ms_per_forward_conv": round(prof.ms_conv, 3),
                 "ms_per_forward_total": round(prof.ms_total, 3), "launches_total": prof.launches}
 
+    # ---- per-stage figures: blue-noise transform vs its HBM / fp32-MFMA rooflines -------------
+    stages = None
+    if rank == 0:
+        def time_noise(nb, reps=20):
+            zz = torch.randn(nb, 3, 64, 64, device=dev)
+            aa = torch.ones(nb, device=dev)
+            tt = torch.full((nb,), N, device=dev)
+            for _ in range(3):
+                get_noise_v2(dev, zz, L, aa, tt, noise_type="GBN", train_or_test="test", inplace=True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                get_noise_v2(dev, zz, L, aa, tt, noise_type="GBN", train_or_test="test", inplace=True)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps * 1e3            # us per call (gemm + finish kernels)
+        TRI = 4096 * 4097 // 2
+        us_small, us_batch = time_noise(2), time_noise(B)
+        n_small, n_batch = 2 * 3, B * 3
+        stages = {
+            "bluenoise_B2_us": round(us_small, 1),
+            "bluenoise_B2_GBps_of_L": round(4 * TRI / (us_small * 1e-6) / 1e9, 1),      # HBM-bound regime (n = 6 columns)
+            "bluenoise_B%d_us" % B: round(us_batch, 1),
+            "bluenoise_B%d_fp32_TFLOPs" % B: round(2.0 * TRI * n_batch / (us_batch * 1e-6) / 1e12, 2),   # fp32-MFMA-bound regime
+            "hbm_peak_GBps": 8000, "fp32_mfma_peak_TFLOPs": 157.3,
+            "unet_ms_per_denoising_step": roof["ms_per_forward_total"] if roof else None,
+        }
+
     if rank == 0:
         imgs = args.gpus * B * args.steps
         line = {
@@ -192,6 +220,7 @@ def main():
                                    f"UNet 3->6, tiled Gaussian blue noise (64^2 tiles from 4096^2 L)",
                        "global_batch": B * args.gpus, "nb_steps": N, "parallelism": f"batch-shard x{args.gpus}"},
             "roofline": roof,
+            "stages": stages,
             "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(N),
         }
         print(json.dumps(line), flush=True)

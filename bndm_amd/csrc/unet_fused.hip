@@ -54,6 +54,7 @@ __global__ __launch_bounds__(NW * 64) void conv_fused(const FusedArgs a, const S
     constexpr int TM = (TH * TW) / (WAVES_M * 32);     // 32-pixel MFMA tiles per wave along M
     static_assert(TM >= 1 && (TH % WAVES_M) == 0 && (TH / WAVES_M) % 2 == 0, "wave tiling");
     constexpr int TN = 2;
+    constexpr bool WREG = (ABL & 64) != 0;             // weight tiles through registers instead of LDS-DMA
     constexpr int WSTAGES = 4;
     constexpr int W_BYTES = 128 * 128;
     constexpr int OFF_W = 2 * PATCH_BYTES;
@@ -177,6 +178,19 @@ __global__ __launch_bounds__(NW * 64) void conv_fused(const FusedArgs a, const S
         if (NWP == 2) glds16(wsrc1 + (size_t)kofs * 2, base + 8192 + w * 1024);
     };
 
+    // register-staged alternative: tile s+2 is loaded to VGPRs in the even phase of step s and written to
+    // LDS buffer (s+2)&1 ... one step later, in the even phase of step s+1 (as tile (s+1)+1)
+    v8 wreg[NWP];
+    auto w_load = [&](int kofs) {
+        wreg[0] = *reinterpret_cast<const v8 *>(wsrc0 + (size_t)kofs * 2);
+        if (NWP == 2) wreg[NWP - 1] = *reinterpret_cast<const v8 *>(wsrc1 + (size_t)kofs * 2);
+    };
+    auto w_store = [&](int buf) {
+        char *base = smem + OFF_W + buf * W_BYTES;
+        *reinterpret_cast<v8 *>(base + tid * 16) = wreg[0];
+        if (NWP == 2) *reinterpret_cast<v8 *>(base + 8192 + tid * 16) = wreg[NWP - 1];
+    };
+
     f32x16 acc[TN][TM];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
@@ -254,7 +268,7 @@ __global__ __launch_bounds__(NW * 64) void conv_fused(const FusedArgs a, const S
             kind = 2;
         }
         asm volatile("" ::: "memory");
-        if (!(ABL & 2)) w_issue(wnext, d.x);
+        if (!WREG && !(ABL & 2)) w_issue(wnext, d.x);
         asm volatile("" ::: "memory");
         if (!(ABL & 8) && d.z < 0) {
             patch_dma((d.z >> 24) & 3, d.z & 0xffff, (d.z >> 23) & 1);
@@ -271,10 +285,17 @@ __global__ __launch_bounds__(NW * 64) void conv_fused(const FusedArgs a, const S
     // ---- prologue: chunk 0 and the first WSTAGES-1 weight tiles in flight together; normalise chunk 0 ----
     patch_dma(0, 0, 0);
     asm volatile("" ::: "memory");
-    w_issue(0, steps[nsteps].x);                        // the table's extra entry carries the k-offsets of steps 0..2
-    w_issue(1, steps[nsteps].y);
-    w_issue(2, steps[nsteps].z);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NWP) : "memory");    // own patch pieces landed (weights may still fly)
+    if (WREG) {
+        w_load(steps[nsteps].x);
+        w_store(0);
+        w_load(steps[nsteps].y);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        w_issue(0, steps[nsteps].x);                    // the table's extra entry carries the k-offsets of steps 0..2
+        w_issue(1, steps[nsteps].y);
+        w_issue(2, steps[nsteps].z);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NWP) : "memory");    // own patch pieces landed (weights may still fly)
+    }
     __syncthreads();                                   // ss table visible (written above by plain stores)
     if (a.seg[0].ss_off >= 0) {
         for (int r = 0; r < NROUND; ++r) {
@@ -284,11 +305,13 @@ __global__ __launch_bounds__(NW * 64) void conv_fused(const FusedArgs a, const S
             xf_math_store(x);
         }
     }
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NWP) : "memory");
+    if (WREG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NWP) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
     int wcur = 0, wnext = WSTAGES - 1;
+    int kx_prev = steps[nsteps].z;                      // k-offset of weight tile s+2 (register-staged path)
     if (grpA) {
         read_frags(dcur.y, 0);
         for (int s = 0; s < nsteps; ++s) {
@@ -299,7 +322,15 @@ __global__ __launch_bounds__(NW * 64) void conv_fused(const FusedArgs a, const S
             const StepDesc dn2 = steps[s + 2 < nsteps ? s + 2 : nsteps - 1];
             // (rounds start two taps after the patch DMA: only one younger weight tile is in flight then)
             const bool dox = !(ABL & 8) && dcur.w < 0 && (last_round_wave || ((dcur.w >> 16) & 7) != NROUND - 1);
-            if (!(ABL & 16) && dox && (dcur.w & (1 << 30))) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWP) : "memory");   // patch DMA landed
+            if (WREG) {
+                // tile s+1 (loaded one step ago) -> LDS, then start loading tile s+2
+                if (s + 1 < nsteps) w_store((s + 1) & 1);
+                if (dox && (dcur.w & (1 << 30))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // patch DMA landed
+                if (s + 2 < nsteps) w_load(kx_prev);
+                kx_prev = dcur.x;
+            } else if (!(ABL & 16) && dox && (dcur.w & (1 << 30))) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWP) : "memory");   // patch DMA landed
+            }
             const int issued = even_dma(dcur, wnext);
             if (dox) {
                 // normalisation arithmetic rides in the shadow of the matrix pipe
@@ -327,7 +358,10 @@ __global__ __launch_bounds__(NW * 64) void conv_fused(const FusedArgs a, const S
                 multiply();
             }
             // weight tile s+1 landed: WSTAGES-2 younger tiles (+ a patch DMA issued after them) may still fly
-            if (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // profiling: never wait for DMA
+            if (WREG) {
+                if (issued == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // late 1x1 patch needed now
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else if (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // profiling: never wait for DMA
             else if (issued == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NWP * (WSTAGES - 2)) : "memory");
             else if (issued == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NWP) : "memory");   // late patch: only the newest tile may fly
             else if (last_round_wave) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NWP * (WSTAGES - 2) + NROUND) : "memory");
@@ -335,7 +369,7 @@ __global__ __launch_bounds__(NW * 64) void conv_fused(const FusedArgs a, const S
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const int wn1 = wcur + 1 == WSTAGES ? 0 : wcur + 1;
-            if (!(ABL & 4) && s + 1 < nsteps) read_frags(dnext.y, wn1);
+            if (!(ABL & 4) && s + 1 < nsteps) read_frags(dnext.y, WREG ? ((s + 1) & 1) : wn1);
             dcur = dnext;
             dnext = dn2;
             wcur = wn1;
@@ -348,19 +382,30 @@ __global__ __launch_bounds__(NW * 64) void conv_fused(const FusedArgs a, const S
             asm volatile("" ::: "memory");
             const StepDesc dn2 = steps[s + 2 < nsteps ? s + 2 : nsteps - 1];
             const bool dox = !(ABL & 8) && dcur.w < 0 && (last_round_wave || ((dcur.w >> 16) & 7) != NROUND - 1);
-            if (!(ABL & 16) && dox && (dcur.w & (1 << 30))) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWP) : "memory");
+            if (WREG) {
+                // tile s+1 (loaded one step ago) -> LDS, then start loading tile s+2
+                if (s + 1 < nsteps) w_store((s + 1) & 1);
+                if (dox && (dcur.w & (1 << 30))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // patch DMA landed
+                if (s + 2 < nsteps) w_load(kx_prev);
+                kx_prev = dcur.x;
+            } else if (!(ABL & 16) && dox && (dcur.w & (1 << 30))) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWP) : "memory");   // patch DMA landed
+            }
             const int issued = even_dma(dcur, wnext);
             if (dox) {
                 // fragment reads first, normalisation arithmetic while they are in flight
                 XfRegs x;
                 xf_load(dcur.w, x);
-                if (!(ABL & 4)) read_frags(dcur.y, wcur);
+                if (!(ABL & 4)) read_frags(dcur.y, WREG ? (s & 1) : wcur);
                 xf_math_store(x);
             } else {
-                if (!(ABL & 4)) read_frags(dcur.y, wcur);
+                if (!(ABL & 4)) read_frags(dcur.y, WREG ? (s & 1) : wcur);
             }
             // weight tile s+1 landed: WSTAGES-2 younger tiles (+ a patch DMA issued after them) may still fly
-            if (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // profiling: never wait for DMA
+            if (WREG) {
+                if (issued == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // late 1x1 patch needed now
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else if (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // profiling: never wait for DMA
             else if (issued == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NWP * (WSTAGES - 2)) : "memory");
             else if (issued == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NWP) : "memory");   // late patch: only the newest tile may fly
             else if (last_round_wave) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NWP * (WSTAGES - 2) + NROUND) : "memory");
@@ -685,6 +730,7 @@ int launch_conv_fused(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
                 case 10: return launch_fused_t<_Float16, 16, 10>(a, st);
                 case 16: return launch_fused_t<_Float16, 16, 16>(a, st);
                 case 32: return launch_fused_t<_Float16, 16, 32>(a, st);
+                case 64: return launch_fused_t<_Float16, 16, 64>(a, st);
                 case 24: return launch_fused_t<_Float16, 16, 24>(a, st);
                 case 15: return launch_fused_t<_Float16, 16, 15>(a, st);
                 default: break;

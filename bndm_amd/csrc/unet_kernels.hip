@@ -450,16 +450,16 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float *__restrict__ 
     const int xx = m & (Wd - 1), yy = (m >> logW) & (H - 1);
     const int nks = KP >> 4;
     v8 bf[4];
-    for (int s = 0; s < 4; ++s) {
+    const int pbase = (yy - ya) * pw + (xx - xa);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {                      // fully unrolled: bf[] must stay in registers
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 16 * s + 8 * kh + j;
-            T v = (T)0.f;
-            if (s < nks && k < 9 * Cin) {
-                const int ci = k / 9, t = k - ci * 9, dy = t / 3, dx = t - dy * 3;      // dy, dx in 0..2
-                v = patch[(ci * ph + (yy - ya + dy)) * pw + (xx - xa + dx)];
-            }
-            bf[s][j] = v;
+            const int kc = k < 9 * Cin ? k : 0;
+            const int ci = kc / 9, t = kc - ci * 9, dy = t / 3, dx = t - dy * 3;        // dy, dx in 0..2
+            const T v = patch[(ci * ph + dy) * pw + dx + pbase];
+            bf[s][j] = k < 9 * Cin ? v : (T)0.f;
         }
     }
     __syncthreads();                                                   // patch is dead: the tile is staged over it
@@ -469,10 +469,12 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float *__restrict__ 
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        for (int s = 0; s < nks; ++s) {
-            const v8 af = *reinterpret_cast<const v8 *>(W16 + (size_t)(n0 + (l & 31)) * KP + 16 * s + 8 * kh);
-            acc = TT<T>::mfma(af, bf[s], acc);
-        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (s < nks) {
+                const v8 af = *reinterpret_cast<const v8 *>(W16 + (size_t)(n0 + (l & 31)) * KP + 16 * s + 8 * kh);
+                acc = TT<T>::mfma(af, bf[s], acc);
+            }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int co = n0 + 8 * g + 4 * kh;
