@@ -297,13 +297,15 @@ __global__ __launch_bounds__(NW * 64) void conv_fused(const FusedArgs a, const S
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NWP) : "memory");    // own patch pieces landed (weights may still fly)
     }
     __syncthreads();                                   // ss table visible (written above by plain stores)
-    if (a.seg[0].ss_off >= 0) {
-        for (int r = 0; r < NROUND; ++r) {
-            if (r == NROUND - 1 && !last_round_wave) break;
-            XfRegs x;
-            xf_load(r << 16, x);
-            xf_math_store(x);
-        }
+    if (!(ABL & 256) && a.seg[0].ss_off >= 0) {
+        // rounds are independent: load them all, then transform (latencies overlap)
+        XfRegs xr[NROUND];
+#pragma unroll
+        for (int r = 0; r < NROUND; ++r)
+            if (r < NROUND - 1 || last_round_wave) xf_load(r << 16, xr[r]);
+#pragma unroll
+        for (int r = 0; r < NROUND; ++r)
+            if (r < NROUND - 1 || last_round_wave) xf_math_store(xr[r]);
     }
     if (WREG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NWP) : "memory");
@@ -422,56 +424,71 @@ __global__ __launch_bounds__(NW * 64) void conv_fused(const FusedArgs a, const S
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();                                   // all LDS reads and tail DMAs done: reuse LDS
 
-    // ---- epilogue 1: bias + time embedding + residual -> 16-bit tile in LDS ([BM][128 ch], swizzled) --
+    if (ABL & 128) return;                             // profiling: no epilogue
+    // ---- epilogue 1: bias + time embedding -> 16-bit tile in LDS ([BM][128 ch], swizzled) ---------------
+    // all per-channel addends are fetched up front (16 independent loads) instead of inside the store loop
     char *stg = smem;
-    const float *tembp = a.temb ? a.temb + (size_t)b * a.temb_bstride + a.temb_off : nullptr;
+    f32x4 addv[TN][4];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) addv[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                addv[i][g] = *reinterpret_cast<const f32x4 *>(a.bias + n0 + wn * 64 + i * 32 + 8 * g + 4 * kh);
+    }
+    if (a.temb) {
+        const float *tembp = a.temb + (size_t)b * a.temb_bstride + a.temb_off;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                addv[i][g] += *reinterpret_cast<const f32x4 *>(tembp + n0 + wn * 64 + i * 32 + 8 * g + 4 * kh);
+    }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int prow = row_base + 2 * j + lr;
         const int pl = prow * TW + lcx;                                   // pixel inside the tile
-        const size_t m = (size_t)(b * H + y0 + prow) * Wd + x0 + lcx;     // global pixel
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cl = wn * 64 + i * 32 + 8 * g + 4 * kh;         // channel inside the block
-                const int co = n0 + cl;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                if (a.bias) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.bias + co);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += bv[e];
-                }
-                if (tembp) {
-                    const f32x4 tv = *reinterpret_cast<const f32x4 *>(tembp + co);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += tv[e];
-                }
-                if (a.resid) {
-                    const v4 rv = *reinterpret_cast<const v4 *>((const T *)a.resid + m * a.Cout + co);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-                }
                 v4 ov;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ov[e] = (T)v[e];
+                for (int e = 0; e < 4; ++e) ov[e] = (T)(acc[i][j][4 * g + e] + addv[i][g][e]);
                 *reinterpret_cast<v4 *>(stg + pl * 256 + ((((cl >> 3) ^ (pl & 15)) << 4) | ((cl & 7) * 2))) = ov;
             }
     }
     __syncthreads();
 
-    // ---- epilogue 2: full-row stores + per-channel statistics of the stored values -------------------
+    // ---- epilogue 2: residual (row-coalesced 16-B reads) + full-row stores + per-channel statistics ------
     constexpr int RPE = NT / 16;                         // pixel rows handled per pass
+    constexpr int NPASS = BM / RPE;
     const int c16 = tid & 15, prw = tid >> 4;            // 16-byte chunk (8 channels), pixel row slot
+    v8 rres[NPASS];
+    if (a.resid) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int pl = prw + RPE * i;
+            const size_t m = (size_t)(b * H + y0 + (pl >> 4)) * Wd + x0 + (pl & 15);
+            rres[i] = *reinterpret_cast<const v8 *>((const T *)a.resid + m * a.Cout + n0 + c16 * 8);
+        }
+    }
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
 #pragma unroll
-    for (int i = 0; i < BM / RPE; ++i) {
+    for (int i = 0; i < NPASS; ++i) {
         const int pl = prw + RPE * i;
-        const v8 v = *reinterpret_cast<const v8 *>(stg + pl * 256 + ((c16 ^ (pl & 15)) << 4));
+        v8 v = *reinterpret_cast<const v8 *>(stg + pl * 256 + ((c16 ^ (pl & 15)) << 4));
+        if (a.resid) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rres[i][e]);
+        }
         const size_t m = (size_t)(b * H + y0 + (pl >> 4)) * Wd + x0 + (pl & 15);
         *reinterpret_cast<v8 *>((T *)a.out + m * a.Cout + n0 + c16 * 8) = v;
 #pragma unroll
@@ -482,7 +499,7 @@ __global__ __launch_bounds__(NW * 64) void conv_fused(const FusedArgs a, const S
         }
     }
     if (a.stats) {
-        float *red = reinterpret_cast<float *>(smem + BM * 256);           // [32][128][2]
+        float *red = reinterpret_cast<float *>(smem + BM * 256);           // [RPE][128][2]
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             red[((prw * 128) + c16 * 8 + e) * 2 + 0] = s1[e];
@@ -490,10 +507,13 @@ __global__ __launch_bounds__(NW * 64) void conv_fused(const FusedArgs a, const S
         }
         __syncthreads();
         if (tid < 256) {
-            const int ch = tid >> 1, which = tid & 1;
+            float part[RPE];
+#pragma unroll
+            for (int r = 0; r < RPE; ++r) part[r] = red[r * 256 + tid];     // independent loads, then a fixed-order sum
             float t = 0.f;
-            for (int r = 0; r < RPE; ++r) t += red[((r * 128) + ch) * 2 + which];
-            a.stats[((size_t)(b * tps + tin) * a.Cout + n0 + ch) * 2 + which] = t;
+#pragma unroll
+            for (int r = 0; r < RPE; ++r) t += part[r];
+            a.stats[((size_t)(b * tps + tin) * a.Cout + n0) * 2 + tid] = t;
         }
     }
 }
@@ -731,6 +751,9 @@ int launch_conv_fused(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
                 case 16: return launch_fused_t<_Float16, 16, 16>(a, st);
                 case 32: return launch_fused_t<_Float16, 16, 32>(a, st);
                 case 64: return launch_fused_t<_Float16, 16, 64>(a, st);
+                case 143: return launch_fused_t<_Float16, 16, 143>(a, st);
+                case 271: return launch_fused_t<_Float16, 16, 271>(a, st);
+                case 399: return launch_fused_t<_Float16, 16, 399>(a, st);
                 case 24: return launch_fused_t<_Float16, 16, 24>(a, st);
                 case 15: return launch_fused_t<_Float16, 16, 15>(a, st);
                 default: break;
