@@ -89,6 +89,7 @@ __global__ __launch_bounds__(NW * 64) void conv_fused(const FusedArgs a, const S
     // ---- patch piece descriptors (independent of the chunk) ----------------------------------------
     int p_lds[NROUND], p_full[NROUND], p_half[NROUND], p_lc[NROUND];
     int p_valid = 0;                                   // bit r: piece of round r is inside the image
+    int p_lcpack = 0;                                  // 3 bits per round: swizzled source chunk
 #pragma unroll
     for (int r = 0; r < NROUND; ++r) {
         const int piece = r * NT + tid;
@@ -98,7 +99,11 @@ __global__ __launch_bounds__(NW * 64) void conv_fused(const FusedArgs a, const S
         const int iy = y0 - 1 + pyy, ix = x0 - 1 + pxx;
         const bool ok = piece < NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)Wd;
         p_lds[r] = piece < NPIECE ? pp * 128 + pch * 16 : -1;
-        p_lc[r] = pch ^ ((pp >> 1) & 7);
+        // swizzle key = patch COLUMN pair: with it the 16 lanes of every ds_read_b128 lane group hit 16
+        // distinct (pixel parity, chunk) bank classes for all nine tap shifts (a key on the linear pixel
+        // index collides between the two image rows of an MFMA tile because the row stride is 18)
+        p_lc[r] = pch ^ ((pxx >> 1) & 7);
+        p_lcpack |= p_lc[r] << (3 * r);
         p_full[r] = ok ? (b * H + iy) * Wd + ix : -1;
         p_half[r] = ok ? (b * (H >> 1) + (iy >> 1)) * (Wd >> 1) + (ix >> 1) : -1;
         p_valid |= ok ? (1 << r) : 0;
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(NW * 64) void conv_fused(const FusedArgs a, const S
         const int round = (xd >> 16) & 7, chunk = xd & 0xffff, buf = (xd >> 23) & 1;
         const int ss_off = seg_of((xd >> 24) & 3).ss_off;
         const int piece = round * NT + tid;
-        const int lc = (piece & 7) ^ ((piece >> 4) & 7);                 // pch ^ ((pp >> 1) & 7), pp = piece >> 3
+        const int lc = (p_lcpack >> (3 * round)) & 7;
         x.addr = smem + buf * PATCH_BYTES + piece * 16;
         x.valid = (p_valid >> round) & 1;
         x.v = *reinterpret_cast<const v8 *>(x.addr);
@@ -221,15 +226,13 @@ __global__ __launch_bounds__(NW * 64) void conv_fused(const FusedArgs a, const S
     for (int j = 0; j < TM; ++j) pr0[j] = (row_base + 2 * j + lr) * PW + lcx;
     const int c0x = kh << 4;
     auto read_frags = [&](int rd, int wbuf) {
-        const int tapoff = rd & 0xffff, pb = rd >> 16;
+        const int tapoff = rd & 0xff, kx = (rd >> 8) & 3, pb = rd >> 16;
         const char *P = smem + pb * PATCH_BYTES;
         const char *Wt = smem + OFF_W + wbuf * W_BYTES;
+        const int kc = ((((lcx + kx) >> 1) & 7) << 4) ^ c0x;
         int xb[TM];
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            const int pr = pr0[j] + tapoff;
-            xb[j] = ((pr << 7) | (((pr >> 1) & 7) << 4)) ^ c0x;
-        }
+        for (int j = 0; j < TM; ++j) xb[j] = ((pr0[j] + tapoff) << 7) | kc;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -682,7 +685,7 @@ std::vector<int> build_fused_steps(const FusedSeg *seg, int nseg, int TH, int nt
         int *d = &out[(size_t)s * 4];
         d[0] = st[std::min(s + 3, n - 1)].kofs;          // weight tile issued at step s: ring depth 4
         const int ky = c.taps == 9 ? c.tap / 3 : 1, kx = c.taps == 9 ? c.tap % 3 : 1;
-        d[1] = (ky * PW + kx) | ((c.cidx & 1) << 16);
+        d[1] = (ky * PW + kx) | (kx << 8) | ((c.cidx & 1) << 16);
         // chunk DMA'd at tap 0 of its 9-tap predecessor
         if (c.taps == 9 && c.tap == 0 && c.cidx + 1 < nchunks) {
             const St &nx = st[first[c.cidx + 1]];
