@@ -121,6 +121,9 @@ int conv_fused_tiles_per_sample(int TH, int H, int W);
 // per-step schedule table of conv_fused (host side; upload and pass as FusedArgs::steps)
 std::vector<int> build_fused_steps(const FusedSeg *seg, int nseg, int TH, int nthreads);
 int conv_fused_threads(int TH);
+// tap-unrolled variant of the same kernel (unet_tap9.hip); used whenever it supports the segment list
+bool conv_tap9_supports(const FusedArgs &a);
+int launch_conv_tap9(int dtype, int TH, const FusedArgs &a, hipStream_t st);
 
 // one-launch GroupNorm(+SiLU) for small per-sample tensors (statistics + apply, one block per sample)
 int launch_gn_small(int dtype, const void *x1, int C1, const void *x2, int C2, int B, int HW, int groups, float eps,

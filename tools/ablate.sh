@@ -1,7 +1,8 @@
 #!/bin/bash
-# profiling aid: per-op timings of the 64x64 fused convs under each ablation of conv_fused
+# profiling aid: per-op timings of the 64x64 fused convs under each ablation of the fused conv kernel
+# usage: tools/ablate.sh [ablation codes...]   (default: 0 15)
 mkdir -p gpurun_out
-for a in 0 15; do
+for a in ${@:-0 15}; do
   BNDM_ABLATE=$a BNDM_PROFILE_DUMP=gpurun_out/abl_$a.txt python bench.py --profile-only --no-cpu-baseline > /dev/null 2>&1
   echo "ABL=$a: $(grep 'up_blocks.5.resnets.0.conv1' gpurun_out/abl_$a.txt | awk '{print $2, $3}')  d0.conv1: $(grep 'down_blocks.0.resnets.0.conv1' gpurun_out/abl_$a.txt | awk '{print $2}')  up4.ups: $(grep 'up_blocks.4.upsamplers' gpurun_out/abl_$a.txt | awk '{print $2}')"
 done
