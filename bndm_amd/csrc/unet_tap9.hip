@@ -32,6 +32,7 @@ constexpr int rounds_at_tap(int nround, int t) {
 }
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef uint32_t u32x4t __attribute__((ext_vector_type(4)));
 
 // Buffer descriptor from values that ARE wave-uniform; the readfirstlanes make that provable to the compiler,
 // which otherwise wraps every buffer instruction in a waterfall loop.
@@ -43,6 +44,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *p, in
                                              __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
+constexpr int TAP9_MAX_CHUNKS = 64;
+
 // wave-uniform description of one 64-channel chunk of a segment
 struct Chunk {
     const void *src;             // the segment's tensor
@@ -53,7 +56,6 @@ struct Chunk {
     int ssbase;                  // float offset of the chunk's scale row in the LDS table, or -1
     int kbase;                   // weight k-offset (elements) of tap 0
     int kstride;                 // k-offset between taps (= C of the segment)
-    int si, ci;                  // segment / chunk index
 };
 
 // ABL: profiling switches (results are wrong when non-zero): 1 no MFMA, 2 no weight DMA, 4 no fragment reads,
@@ -78,6 +80,7 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
     constexpr int WSTAGES = 4, W_BYTES = 128 * 128;
     constexpr int OFF_W = 2 * PATCH_BYTES;
     constexpr int OFF_SS = OFF_W + WSTAGES * W_BYTES;
+    constexpr int OFF_TAB = OFF_SS + 8192;             // chunk descriptors, 32 B each (TAP9_MAX_CHUNKS of them)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -135,25 +138,61 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
         c.ssbase = ss >= 0 ? ss + ci * 64 : -1;
         c.kbase = pick(si, sg_k0) + ci * 64;
         c.kstride = C;
-        c.si = si;
-        c.ci = ci;
         return c;
     };
-    int nseg9 = 0, nchunk9 = 0, nchunk1 = 0;           // 3x3 segments come first (checked by the launcher)
+    int nchunk9 = 0, nchunk1 = 0;           // 3x3 segments come first (checked by the launcher)
 #pragma unroll
     for (int i = 0; i < CONV_MAX_SEG; ++i)
         if (i < a.nseg) {
             if (a.seg[i].taps == 9) {
-                ++nseg9;
                 nchunk9 += a.seg[i].C >> 6;
             } else {
                 nchunk1 += a.seg[i].C >> 6;
             }
         }
-    // successor within the same class of segments; the last chunk of a class is its own successor
-    auto next_chunk = [&](const Chunk &c, int seg_end) {
-        if (c.ci + 1 < (c.kstride >> 6)) return make_chunk(c.si, c.ci + 1);
-        if (c.si + 1 < seg_end) return make_chunk(c.si + 1, 0);
+    // Chunk descriptors of the whole K loop (3x3 chunks first, then the 1x1 ones) are built once by the first
+    // threads and kept in LDS: advancing to the next chunk is two broadcast ds_reads + readfirstlanes instead
+    // of ~170 scalar instructions of select chains per chunk and wave.
+    if (tid < nchunk9 + nchunk1) {
+        int rem = tid, si = 0, ci = 0;
+        bool found = false;
+#pragma unroll
+        for (int i = 0; i < CONV_MAX_SEG; ++i) {
+            const int nci = sg_C[i] >> 6;
+            if (!found && rem < nci) {
+                si = i;
+                ci = rem;
+                found = true;
+            }
+            rem -= nci;
+        }
+        const Chunk c = make_chunk(si, ci);
+        u32x4t lo, hi;
+        lo[0] = (uint32_t)(uint64_t)c.src;
+        lo[1] = (uint32_t)((uint64_t)c.src >> 32);
+        lo[2] = (uint32_t)c.bytes;
+        lo[3] = (uint32_t)c.soff;
+        hi[0] = (uint32_t)c.C2 | ((uint32_t)c.up << 31);
+        hi[1] = (uint32_t)c.ssbase;
+        hi[2] = (uint32_t)c.kbase;
+        hi[3] = 0;
+        *reinterpret_cast<u32x4t *>(smem + OFF_TAB + tid * 32) = lo;
+        *reinterpret_cast<u32x4t *>(smem + OFF_TAB + tid * 32 + 16) = hi;
+    }
+    auto load_chunk = [&](int n) {
+        const u32x4t lo = *reinterpret_cast<const u32x4t *>(smem + OFF_TAB + n * 32);
+        const u32x4t hi = *reinterpret_cast<const u32x4t *>(smem + OFF_TAB + n * 32 + 16);
+        Chunk c;
+        const uint32_t plo = __builtin_amdgcn_readfirstlane(lo[0]), phi = __builtin_amdgcn_readfirstlane(lo[1]);
+        c.src = (const void *)(((uint64_t)phi << 32) | plo);
+        c.bytes = __builtin_amdgcn_readfirstlane(lo[2]);
+        c.soff = __builtin_amdgcn_readfirstlane(lo[3]);
+        const uint32_t cu = __builtin_amdgcn_readfirstlane(hi[0]);
+        c.C2 = cu & 0x7fffffff;
+        c.up = cu >> 31;
+        c.ssbase = __builtin_amdgcn_readfirstlane(hi[1]);
+        c.kbase = __builtin_amdgcn_readfirstlane(hi[2]);
+        c.kstride = c.C2 >> 1;
         return c;
     };
 
@@ -287,7 +326,7 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
     // scale/shift table (one 16-byte piece per thread, zeros past its end), patch of chunk 0, weight tiles of
     // taps 0..2 -- all by LDS-DMA, so they retire in issue order and one counted wait separates them
     Chunk cur = make_chunk(0, 0);
-    Chunk nxt = next_chunk(cur, nseg9);
+    Chunk nxt = cur;
     {
         const __amdgpu_buffer_rsrc_t srs =
             uniform_rsrc(a.ss ? a.ss + (size_t)b * 2 * a.ssC : (const float *)a.zeros, a.ss ? 2 * a.ssC * 4 : 0);
@@ -331,6 +370,7 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (nchunk9 > 1) nxt = load_chunk(1);
 
     // ---- 3x3 chunks -----------------------------------------------------------------------------------
     // Step t of a chunk (tap t) runs four k16 phases; the fragments of phase p+2 are read while the MFMAs of
@@ -408,7 +448,7 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
                     for (int ks = 0; ks < 4; ++ks) pa[kx][ks] += d;
                 pbuf ^= 1;
                 cur = nxt;
-                nxt = next_chunk(nxt, nseg9);
+                nxt = load_chunk(c + 2 < nchunk9 ? c + 2 : nchunk9 - 1);
             }
             constexpr int N = rounds_at_tap(NROUND, t - 2 < 0 ? t - 2 + 9 : t - 2) + 2 +
                               rounds_at_tap(NROUND, t - 1 < 0 ? t - 1 + 9 : t - 1);
@@ -461,7 +501,7 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
 
     // ---- 1x1 chunks (raw centre pixels; patch + weight tile of chunk n+1 fly while chunk n multiplies) ----
     if (nchunk1 > 0) {
-        Chunk c1 = make_chunk(nseg9, 0);
+        Chunk c1 = load_chunk(nchunk9);
         auto issue1 = [&](const Chunk &c, int buf) {
             auto issue_all = [&](auto self, auto rc) {
                 constexpr int r = decltype(rc)::value;
@@ -478,7 +518,7 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            const Chunk c2 = next_chunk(c1, a.nseg);
+            const Chunk c2 = load_chunk(nchunk9 + (n + 1 < nchunk1 ? n + 1 : nchunk1 - 1));
             if (n + 1 < nchunk1) issue1(c2, (n + 1) & 1);
             const int buf = n & 1;
 #pragma unroll
@@ -601,7 +641,7 @@ int launch_tap9_t(const FusedArgs &a, hipStream_t st) {
     constexpr int NPIECE = (TH + 2) * 18 * 8, NROUND = (NPIECE + NT - 1) / NT;
     constexpr int NREMW = (NPIECE - (NROUND - 1) * NT + 63) / 64;
     constexpr int PATCH_BYTES = (NROUND - 1) * NT * 16 + NREMW * 1024 + (NREMW < 8 ? 1024 : 0);
-    constexpr int main_bytes = 2 * PATCH_BYTES + 4 * 16384 + 8192;
+    constexpr int main_bytes = 2 * PATCH_BYTES + 4 * 16384 + 8192 + TAP9_MAX_CHUNKS * 32;
     constexpr int epi_bytes = TH * 16 * 256 + (NT / 16) * 128 * 2 * 4;
     constexpr int smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
     static_assert(smem <= 160 * 1024, "LDS budget");
@@ -648,11 +688,13 @@ int launch_tap9_t(const FusedArgs &a, hipStream_t st) {
 // true when conv_tap9 can run this segment list: 3x3 segments first, 1x1 segments after them
 bool conv_tap9_supports(const FusedArgs &a) {
     bool seen1 = false;
+    int nchunks = 0;
     for (int i = 0; i < a.nseg; ++i) {
         if (a.seg[i].taps == 1) seen1 = true;
         else if (seen1) return false;
+        nchunks += a.seg[i].C / 64;
     }
-    return a.nseg >= 1 && a.seg[0].taps == 9;
+    return a.nseg >= 1 && a.seg[0].taps == 9 && nchunks <= TAP9_MAX_CHUNKS;
 }
 
 int launch_conv_tap9(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
