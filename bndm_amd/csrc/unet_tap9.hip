@@ -26,9 +26,17 @@ template <int N> struct IC {
     static constexpr int value = N;
 };
 
-// patch DMA rounds issued after the barrier of tap t (two per tap from tap 0 on)
+// patch DMA rounds issued after the barrier of tap t (three per tap from tap 0 on); t is taken modulo 9
 constexpr int rounds_at_tap(int nround, int t) {
-    return t < 0 || t > 2 ? 0 : (nround - 2 * t >= 2 ? 2 : (nround - 2 * t > 0 ? nround - 2 * t : 0));
+    t = ((t % 9) + 9) % 9;
+    return t > 1 ? 0 : (nround - 3 * t >= 3 ? 3 : (nround - 3 * t > 0 ? nround - 3 * t : 0));
+}
+// DMAs a thread has issued after patch round r by the end of group G_s (see the loop comment)
+constexpr int dmas_after_round(int nround, int r, int s) {
+    const int g = r / 3;
+    int n = (3 * g + 2 < nround - 1 ? 3 * g + 2 : nround - 1) - r;
+    for (int j = g + 1; j <= s; ++j) n += 2 + rounds_at_tap(nround, j);
+    return n;
 }
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
 
     // ---- prologue -------------------------------------------------------------------------------------
     // scale/shift table (one 16-byte piece per thread, zeros past its end), patch of chunk 0, weight tiles of
-    // taps 0..2 -- all by LDS-DMA, so they retire in issue order and one counted wait separates them
+    // taps 0..3 -- all by LDS-DMA, so they retire in issue order and one counted wait separates them
     Chunk cur = make_chunk(0, 0);
     Chunk nxt = cur;
     {
@@ -345,7 +353,8 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
         w_issue(0, cur.kbase);
         w_issue(1, cur.kbase + cur.kstride);
         w_issue(2, cur.kbase + 2 * cur.kstride);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // table + own patch pieces landed
+        w_issue(3, cur.kbase + 3 * cur.kstride);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // table + own patch pieces landed
         __builtin_amdgcn_s_barrier();                         // ... in every wave (the table is shared)
         asm volatile("" ::: "memory");
         if (!(ABL & 8) && cur.ssbase >= 0) {
@@ -375,14 +384,17 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
     // ---- 3x3 chunks -----------------------------------------------------------------------------------
     // Step t of a chunk (tap t) runs four k16 phases; the fragments of phase p+2 are read while the MFMAs of
     // phase p run (three register sets, set = p % 3; a chunk has 36 phases, so the assignment is static).
-    // Barrier B_t sits between phases 1 and 2: it certifies weight tile t+1 (and, at t = 8, the normalised
-    // patch of the next chunk) for the reads issued after it, and releases ring slot (t-1) & 3 and (at t = 0)
-    // the other patch buffer for the DMAs issued right after it:
-    //     G_t = [ weight tile t+3 (2 pieces), patch rounds 2t, 2t+1 of the next chunk (t = 0..2) ]
-    // vmcnt before B_t must certify the tile issued in G_(t-2); younger than it are the patch pieces of
-    // G_(t-2) and all of G_(t-1):  N_t = np(t-2) + 2 + np(t-1).  Patch round r is therefore certified by B_(r/2+3)
-    // and is normalised by its issuing thread between B_s and B_(s+1), s = 3 + r (rounds >= 4: s = 7), in four
-    // slices that ride in the shadow of the 16 MFMAs of that window; B_8 (with lgkmcnt(0)) publishes them.
+    // Barrier B_t sits between phases 1 and 2.  Every wave reaches it with lgkmcnt(0), i.e. with all its reads of
+    // weight tile t (and, at t = 8, its normalisation writes) complete, and with tile t+1 landed (vmcnt), so
+    // after B_t tile t+1 (at t = 8 also the next chunk's patch) may be read and the DMA group
+    //     G_t = [ weight tile t+4 -> the ring slot of tile t (2 pieces), patch rounds 3t..3t+2 of the next chunk
+    //             into the other patch buffer (t = 0, 1) ]
+    // is issued: every tile has three full steps to land.  vmcnt before B_t certifies the tile issued in G_(t-3);
+    // younger are the patch pieces of G_(t-3) and all of G_(t-2), G_(t-1):
+    //     N_t = np(t-3) + 2 + np(t-2) + 2 + np(t-1).
+    // Patch round r is normalised in place by its issuing thread between B_s and B_(s+1), s = 3 + r (rounds >= 4:
+    // s = 7), in four slices that ride in the shadow of the 16 MFMAs of that window; the window opens with its own
+    // counted wait (dmas_after_round) for that piece, normally long satisfied; B_8 publishes the patch.
     int slot = 0;                                        // ring slot of the current step's weight tile
     int pbuf = 0;                                        // patch buffer of the current chunk
     if (nchunk9 > 0) {
@@ -399,12 +411,16 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
             constexpr int s = decltype(sc)::value, wpos = decltype(wc)::value;
             constexpr int r = s >= 3 && s <= 7 && s - 3 < NROUND ? s - 3 : -1;
             if constexpr (r >= 0) {
+                if constexpr (wpos == 0 && !(ABL & 128))
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dmas_after_round(NROUND, r, s)) : "memory");
                 if (dox && xf_owner(r)) {
                     if constexpr (wpos == 0) xf_begin(IC<r>{}, pbuf ^ 1, xa);
                     xf_slice(IC<r>{}, wc, nxt, xa);
                     if constexpr (wpos == 3) xf_end(IC<r>{}, pbuf ^ 1, xa);
                 }
                 if constexpr (s == 7 && NROUND > 5) {
+                    if constexpr (wpos == 0 && !(ABL & 128))
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dmas_after_round(NROUND, 5, s)) : "memory");
                     if (dox && xf_owner(5)) {
                         if constexpr (wpos == 0) xf_begin(IC<5>{}, pbuf ^ 1, xb);
                         xf_slice(IC<5>{}, wc, nxt, xb);
@@ -450,12 +466,11 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
                 cur = nxt;
                 nxt = load_chunk(c + 2 < nchunk9 ? c + 2 : nchunk9 - 1);
             }
-            constexpr int N = rounds_at_tap(NROUND, t - 2 < 0 ? t - 2 + 9 : t - 2) + 2 +
-                              rounds_at_tap(NROUND, t - 1 < 0 ? t - 1 + 9 : t - 1);
+            constexpr int N = rounds_at_tap(NROUND, t - 3) + 2 + rounds_at_tap(NROUND, t - 2) + 2 +
+                              rounds_at_tap(NROUND, t - 1);
             mark(t, 1);
             if constexpr ((ABL & 128) != 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            else if constexpr (t == 8) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
             mark(t, 2);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -463,17 +478,17 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
             // phase 2
             read_frags(IC<(t + 1) % 9>{}, IC<0>{}, IC<(p0 + 4) % 3>{});
             if (!(ABL & 2)) {
-                // tile of step t+3: after the advance above `cur` is already the next chunk at t = 8
-                const int kofs = t + 3 < 9 ? cur.kbase + (t + 3) * cur.kstride
-                                 : t == 8  ? cur.kbase + 2 * cur.kstride
-                                           : nxt.kbase + (t + 3 - 9) * nxt.kstride;
-                w_issue((slot + 2) & (WSTAGES - 1), kofs);       // slot was advanced: (old slot + 3) & 3
+                // tile of step t+4: after the advance above `cur` is already the next chunk at t = 8
+                const int kofs = t + 4 < 9 ? cur.kbase + (t + 4) * cur.kstride
+                                 : t == 8  ? cur.kbase + 3 * cur.kstride
+                                           : nxt.kbase + (t + 4 - 9) * nxt.kstride;
+                w_issue((slot + 3) & (WSTAGES - 1), kofs);       // slot was advanced: the slot of tile t
             }
             if constexpr (rounds_at_tap(NROUND, t) > 0) {
                 if (!(ABL & 8)) {
-                    patch_dma(IC<2 * t>{}, nxt, pbuf ^ 1);
-                    if constexpr (rounds_at_tap(NROUND, t) > 1)
-                        patch_dma(IC<(2 * t + 1 < NROUND ? 2 * t + 1 : 0)>{}, nxt, pbuf ^ 1);
+                    patch_dma(IC<3 * t>{}, nxt, pbuf ^ 1);
+                    if constexpr (rounds_at_tap(NROUND, t) > 1) patch_dma(IC<(3 * t + 1 < NROUND ? 3 * t + 1 : 0)>{}, nxt, pbuf ^ 1);
+                    if constexpr (rounds_at_tap(NROUND, t) > 2) patch_dma(IC<(3 * t + 2 < NROUND ? 3 * t + 2 : 0)>{}, nxt, pbuf ^ 1);
                 }
             }
             multiply(IC<(p0 + 2) % 3>{});
