@@ -499,13 +499,16 @@ struct Builder {
             const int M = r.B * c.H * c.W;
             int tile = TILE_256x128;
             int nblk = ceil_div(M, 256) * ceil_div(c.Cout, 128);
-            if (nblk < 192) {
+            static const int big_min_m = getenv("BNDM_SPLITK_BIG_M") ? atoi(getenv("BNDM_SPLITK_BIG_M")) : (1 << 30);
+            if (nblk < 192 && M < big_min_m) {
                 tile = TILE_128x128;
                 nblk = ceil_div(M, 128) * ceil_div(c.Cout, 128);
             }
             int splitk = 1;
+            static const int sk_target = getenv("BNDM_SPLITK_TARGET") ? atoi(getenv("BNDM_SPLITK_TARGET")) : 256;
+            static const int sk_minsteps = getenv("BNDM_SPLITK_MINSTEPS") ? atoi(getenv("BNDM_SPLITK_MINSTEPS")) : 8;
             if (nblk < 192 && ksteps >= 8) {
-                splitk = std::min(std::min(ceil_div(512, nblk), ksteps / 4), 32);
+                splitk = std::min(std::min(ceil_div(sk_target, nblk), ksteps / sk_minsteps), 32);
                 if (splitk >= 2) {
                     const int per = ceil_div(ksteps, splitk);
                     splitk = ceil_div(ksteps, per);          // no empty slices
