@@ -765,7 +765,10 @@ int launch_conv_t(int tile, int epi, const ConvArgs &a, hipStream_t st) {
     if (tile == TILE_256x128) {      // 8 waves, 3-stage ring (144 KB LDS, one block per CU)
         if (epi == EPI_NHWC16) return launch_conv_cfg<T, 4, 2, 2, 2, EPI_NHWC16, 3>(a, st);
         if (epi == EPI_F32_ROWS) return launch_conv_cfg<T, 4, 2, 2, 2, EPI_F32_ROWS, 3>(a, st);
-    } else if (tile == TILE_128x128) {   // 4 waves, 4-stage ring (128 KB LDS)
+    } else if (tile == TILE_128x128) {   // 4-stage ring (128 KB LDS); 8 waves (32x64 wave tiles) or 4 (64x64)
+        static const int w8 = getenv("BNDM_IGEMM_W8") ? atoi(getenv("BNDM_IGEMM_W8")) : 1;
+        if (w8 && epi == EPI_NHWC16) return launch_conv_cfg<T, 4, 2, 1, 2, EPI_NHWC16, 4>(a, st);
+        if (w8 && epi == EPI_F32_ROWS) return launch_conv_cfg<T, 4, 2, 1, 2, EPI_F32_ROWS, 4>(a, st);
         if (epi == EPI_NHWC16) return launch_conv_cfg<T, 2, 2, 2, 2, EPI_NHWC16, 4>(a, st);
         if (epi == EPI_F32_ROWS) return launch_conv_cfg<T, 2, 2, 2, 2, EPI_F32_ROWS, 4>(a, st);
         if (epi == EPI_SPLITK_FUSED) return launch_conv_cfg<T, 2, 2, 2, 2, EPI_SPLITK_FUSED, 4>(a, st);
