@@ -401,31 +401,76 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
         read_frags(IC<0>{}, IC<0>{}, IC<0>{});
         read_frags(IC<0>{}, IC<1>{}, IC<1>{});
     }
-    static_assert(NROUND <= 6, "normalisation schedule covers 6 rounds");
-    for (int c = 0; c < nchunk9; ++c) {
-        const bool has_next = c + 1 < nchunk9;
-        const bool dox = !(ABL & 8) && !(ABL & 16) && has_next && nxt.ssbase >= 0;
-        u32x4 xa, xb;                                    // round in flight (xb: the partial last round)
-        // window position w (0: phase 2 of step s, 1: phase 3, 2: phase 0 of s+1, 3: phase 1 of s+1)
-        auto xf_window = [&](auto sc, auto wc) {
-            constexpr int s = decltype(sc)::value, wpos = decltype(wc)::value;
-            constexpr int r = s >= 3 && s <= 7 && s - 3 < NROUND ? s - 3 : -1;
-            if constexpr (r >= 0) {
-                if constexpr (wpos == 0 && !(ABL & 128))
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dmas_after_round(NROUND, r, s)) : "memory");
-                if (dox && xf_owner(r)) {
-                    if constexpr (wpos == 0) xf_begin(IC<r>{}, pbuf ^ 1, xa);
-                    xf_slice(IC<r>{}, wc, nxt, xa);
-                    if constexpr (wpos == 3) xf_end(IC<r>{}, pbuf ^ 1, xa);
+    static_assert(NROUND - (NREMW < 8 ? 1 : 0) <= 5, "normalisation schedule: five full rounds + a partial one");
+    // The chunk body is instantiated with (DOX) and without the normalisation of the next chunk's patch, so that
+    // the slices sit in the same basic block as the MFMAs and are interleaved with them.  A conv's 3x3 segments
+    // are either all normalised or none (checked by the launcher): the loop over chunks 0..n-2 uses one variant,
+    // the last chunk (no successor to prepare) always the plain one.
+    auto chunk_body = [&](auto doxc, const int c) __attribute__((always_inline)) {
+        constexpr bool DOX = decltype(doxc)::value != 0 && !(ABL & 8) && !(ABL & 16);
+        constexpr int NFULL = NROUND - (NREMW < 8 ? 1 : 0);    // rounds in which every wave owns pieces
+        u32x4 xa = {0u, 0u, 0u, 0u}, xb = {0u, 0u, 0u, 0u};    // round in flight (xb: the partial last round)
+        f32x2 sa = {0.f, 0.f}, ha = {0.f, 0.f};                // scale / shift of the slice in flight
+        // window of step s: positions 0..3 = phase 2, 3 of step s and phase 0, 1 of step s+1
+        // xf_pre: LDS reads of the position, issued before the fragment reads of the phase
+        auto xf_pre = [&](auto sc, auto wc) {
+            constexpr int s = decltype(sc)::value, q = decltype(wc)::value;
+            constexpr int r = s >= 3 && s <= 7 && s - 3 < NFULL ? s - 3 : -1;
+            if constexpr (DOX && r >= 0) {
+                if constexpr (q == 0) {
+                    // own piece landed?  (G_s is issued later in this phase: count up to G_(s-1))
+                    if constexpr (!(ABL & 128))
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dmas_after_round(NROUND, r, s - 1)) : "memory");
+                    xf_begin(IC<r>{}, pbuf ^ 1, xa);
                 }
-                if constexpr (s == 7 && NROUND > 5) {
-                    if constexpr (wpos == 0 && !(ABL & 128))
-                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dmas_after_round(NROUND, 5, s)) : "memory");
-                    if (dox && xf_owner(5)) {
-                        if constexpr (wpos == 0) xf_begin(IC<5>{}, pbuf ^ 1, xb);
-                        xf_slice(IC<5>{}, wc, nxt, xb);
-                        if constexpr (wpos == 3) xf_end(IC<5>{}, pbuf ^ 1, xb);
-                    }
+                const int lc = (p_lcpack >> (3 * r)) & 7;
+                const float *sc = ssL + nxt.ssbase + lc * 8 + 2 * q;
+                sa = *reinterpret_cast<const f32x2 *>(sc);
+                ha = *reinterpret_cast<const f32x2 *>(sc + a.ssC);
+            }
+        };
+        auto xf_math = [&](auto sc, auto wc) {
+            constexpr int s = decltype(sc)::value, q = decltype(wc)::value;
+            constexpr int r = s >= 3 && s <= 7 && s - 3 < NFULL ? s - 3 : -1;
+            if constexpr (DOX && r >= 0) {
+                const bool valid = (p_valid >> r) & 1;
+                const unsigned xq = xa[q];
+                const v2 in = __builtin_bit_cast(v2, xq);
+                v2 o;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float f = fmaf((float)in[e], sa[e], ha[e]);
+                    o[e] = (T)(f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f)));
+                }
+                xa[q] = valid ? __builtin_bit_cast(unsigned, o) : xq;
+                if constexpr (q == 3) xf_end(IC<r>{}, pbuf ^ 1, xa);
+            }
+        };
+        // the partial last round (pieces of waves < NREMW only) slice by slice in the window of step 7
+        auto xf_tail = [&](auto sc, auto wc) {
+            constexpr int s = decltype(sc)::value, q = decltype(wc)::value;
+            if constexpr (DOX && NREMW < 8 && s == 7) {
+                constexpr int r = NROUND - 1;
+                if constexpr (q == 0 && !(ABL & 128))
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dmas_after_round(NROUND, r, s)) : "memory");
+                if (w < NREMW) {
+                    if constexpr (q == 0) xf_begin(IC<r>{}, pbuf ^ 1, xb);
+                    xf_slice(IC<r>{}, wc, nxt, xb);
+                    if constexpr (q == 3) xf_end(IC<r>{}, pbuf ^ 1, xb);
+                }
+            }
+        };
+        // MFMAs of one phase with the slice of the window interleaved (1 MFMA : a few VALU)
+        auto phase_math = [&](auto setc, auto sc, auto wc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr int r = s >= 3 && s <= 7 && s - 3 < NFULL ? s - 3 : -1;
+            multiply(setc);
+            xf_math(sc, wc);
+            if constexpr (DOX && r >= 0 && !(ABL & 1) && !(ABL & 256)) {
+#pragma unroll
+                for (int g = 0; g < TN * TM; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 20 / (TN * TM), 0);       // VALU in its shadow
                 }
             }
         };
@@ -442,13 +487,15 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
             constexpr int p0 = 4 * t;
             mark(t, 0);
             // phase 0
+            xf_pre(IC<t - 1>{}, IC<2>{});
             read_frags(tc, IC<2>{}, IC<(p0 + 2) % 3>{});
-            multiply(IC<p0 % 3>{});
-            xf_window(IC<t - 1>{}, IC<2>{});
+            phase_math(IC<p0 % 3>{}, IC<t - 1>{}, IC<2>{});
+            xf_tail(IC<t - 1>{}, IC<2>{});
             // phase 1
+            xf_pre(IC<t - 1>{}, IC<3>{});
             read_frags(tc, IC<3>{}, IC<(p0 + 3) % 3>{});
-            multiply(IC<(p0 + 1) % 3>{});
-            xf_window(IC<t - 1>{}, IC<3>{});
+            phase_math(IC<(p0 + 1) % 3>{}, IC<t - 1>{}, IC<3>{});
+            xf_tail(IC<t - 1>{}, IC<3>{});
             // advance the weight ring (and, at the last tap, the chunk) before the reads of the next step
             {
                 const int d = slot == WSTAGES - 1 ? -(WSTAGES - 1) * W_BYTES : W_BYTES;
@@ -476,6 +523,7 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
             asm volatile("" ::: "memory");
             mark(t, 3);
             // phase 2
+            xf_pre(tc, IC<0>{});
             read_frags(IC<(t + 1) % 9>{}, IC<0>{}, IC<(p0 + 4) % 3>{});
             if (!(ABL & 2)) {
                 // tile of step t+4: after the advance above `cur` is already the next chunk at t = 8
@@ -491,13 +539,14 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
                     if constexpr (rounds_at_tap(NROUND, t) > 2) patch_dma(IC<(3 * t + 2 < NROUND ? 3 * t + 2 : 0)>{}, nxt, pbuf ^ 1);
                 }
             }
-            multiply(IC<(p0 + 2) % 3>{});
-            xf_window(tc, IC<0>{});
+            phase_math(IC<(p0 + 2) % 3>{}, tc, IC<0>{});
+            xf_tail(tc, IC<0>{});
             mark(t, 4);
             // phase 3
+            xf_pre(tc, IC<1>{});
             read_frags(IC<(t + 1) % 9>{}, IC<1>{}, IC<(p0 + 5) % 3>{});
-            multiply(IC<(p0 + 3) % 3>{});
-            xf_window(tc, IC<1>{});
+            phase_math(IC<(p0 + 3) % 3>{}, tc, IC<1>{});
+            xf_tail(tc, IC<1>{});
             mark(t, 5);
         };
         step(IC<0>{});
@@ -509,6 +558,14 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
         step(IC<6>{});
         step(IC<7>{});
         step(IC<8>{});
+    };
+    if (nchunk9 > 0) {
+        if (cur.ssbase >= 0) {
+            for (int c = 0; c + 1 < nchunk9; ++c) chunk_body(IC<1>{}, c);
+        } else {
+            for (int c = 0; c + 1 < nchunk9; ++c) chunk_body(IC<0>{}, c);
+        }
+        chunk_body(IC<0>{}, nchunk9 - 1);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -707,6 +764,7 @@ bool conv_tap9_supports(const FusedArgs &a) {
     for (int i = 0; i < a.nseg; ++i) {
         if (a.seg[i].taps == 1) seen1 = true;
         else if (seen1) return false;
+        else if ((a.seg[i].ss_off >= 0) != (a.seg[0].ss_off >= 0)) return false;   // all 3x3 segments normalised, or none
         nchunks += a.seg[i].C / 64;
     }
     return a.nseg >= 1 && a.seg[0].taps == 9 && nchunks <= TAP9_MAX_CHUNKS;
