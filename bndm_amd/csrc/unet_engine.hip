@@ -50,6 +50,33 @@ struct Buf {
     void *ptr = nullptr;
 };
 
+// tile / split-K choice of the generic conv path (shared by the conv launch and by the consumer of deferred slabs)
+struct ConvPlan {
+    int tile, splitk;
+};
+static ConvPlan plan_conv(int M, int Cout, int ksteps, size_t splitk_bytes) {
+    int tile = TILE_256x128;
+    int nblk = ceil_div(M, 256) * ceil_div(Cout, 128);
+    static const int big_min_m = getenv("BNDM_SPLITK_BIG_M") ? atoi(getenv("BNDM_SPLITK_BIG_M")) : (1 << 30);
+    if (nblk < 192 && M < big_min_m) {
+        tile = TILE_128x128;
+        nblk = ceil_div(M, 128) * ceil_div(Cout, 128);
+    }
+    int splitk = 1;
+    static const int sk_target = getenv("BNDM_SPLITK_TARGET") ? atoi(getenv("BNDM_SPLITK_TARGET")) : 256;
+    static const int sk_minsteps = getenv("BNDM_SPLITK_MINSTEPS") ? atoi(getenv("BNDM_SPLITK_MINSTEPS")) : 8;
+    if (nblk < 192 && ksteps >= 8) {
+        splitk = std::min(std::min(ceil_div(sk_target, nblk), ksteps / sk_minsteps), 32);
+        if (splitk >= 2) {
+            const int per = ceil_div(ksteps, splitk);
+            splitk = ceil_div(ksteps, per);          // no empty slices
+        }
+        if (splitk < 2) splitk = 1;
+    }
+    if ((size_t)splitk * M * Cout * 4 > splitk_bytes) splitk = 1;
+    return ConvPlan{tile, splitk};
+}
+
 struct Act {       // NHWC 16-bit activation living in buffer slot `slot`
     int slot;
     int C, H, W;
@@ -284,6 +311,7 @@ struct Builder {
     int temb_cursor = 0;
     bool use_fused = true;
     bool use_gn_small = true;
+    bool use_defer = true;                 // split-K slabs summed by the consuming gn_small
     int fused_min = 16, fused_max = 1 << 20;   // resolutions (H) handled by the fused conv path
     std::unordered_map<int, StatRef> stats_of;   // activation slot -> cached GroupNorm partial sums
     std::vector<float> tp_w, tp_b;      // concatenated time_emb_proj [ntemb][temb_dim], [ntemb]
@@ -324,6 +352,7 @@ struct Builder {
 
     // scale/shift table of GroupNorm(32)(cat(x1, x2)) -> scratch slot s_ss
     void gn_table(const Act &x1, const Act *x2, const std::string &pname) {
+        materialize();
         bndm_unet *hh = h;
         const int C1 = x1.C, C2 = x2 ? x2->C : 0, C = C1 + C2, HW = x1.H * x1.W;
         const StatRef a1 = ensure_stats(x1);
@@ -350,13 +379,34 @@ struct Builder {
             if ((rc = upload_f32(h, h->hp(pname + ".weight"), &gamma))) return;
             if ((rc = upload_f32(h, h->hp(pname + ".bias"), &beta))) return;
             const int s1 = x1.slot, s2 = x2 ? x2->slot : -1, so = out.slot;
+            const bool fused_reduce = pend.slot == x1.slot;
+            const Pending q = pend;
+            if (fused_reduce) pend.slot = -1;
+            else materialize();
             cur_name = S("gnsm %-44s C=%-4d %dx%d", pname.c_str(), C1 + C2, x1.H, x1.W);
             push(OPC_OTHER, 0, [=](RunCtx &r) {
+                GnSlabSrc sl;
+                if (fused_reduce) {
+                    const ConvPlan pl = plan_conv(r.B * HW, C1, q.ksteps, hh->bufs[hh->s_splitk].bytes);
+                    if (pl.splitk > 1) {
+                        sl.part = (const float *)hh->P(hh->s_splitk);
+                        sl.splitk = pl.splitk;
+                        sl.bias = q.bias;
+                        if (q.temb_off >= 0) {
+                            sl.temb = r.tp_row ? r.tp_row : (const float *)hh->P(hh->s_tp);
+                            sl.temb_bstride = r.tp_row ? 0 : hh->ntemb;
+                            sl.temb_off = q.temb_off;
+                        }
+                        sl.resid = q.rs >= 0 ? hh->P(q.rs) : nullptr;
+                        sl.raw_out = hh->P(s1);
+                    }
+                }
                 return launch_gn_small(hh->dtype(), hh->P(s1), C1, s2 >= 0 ? hh->P(s2) : nullptr, C2, r.B, HW, GROUPS,
-                                       GN_EPS, gamma, beta, silu ? 1 : 0, hh->P(so), r.st);
+                                       GN_EPS, gamma, beta, silu ? 1 : 0, hh->P(so), r.st, sl.part ? &sl : nullptr);
             });
             return;
         }
+        materialize();
         gn_table(x1, x2, pname);
         if (rc) return;
         const int s1 = x1.slot, s2 = x2 ? x2->slot : -1, so = out.slot;
@@ -378,6 +428,7 @@ struct Builder {
     void conv_fused(const std::vector<FIn> &ins, bool normed, int ssC, bool silu, const void *Wp, int Ktot,
                     const float *bias, int temb_off, const Act *resid, const Act &out, bool want_stats,
                     const std::string &label) {
+        materialize();
         bndm_unet *hh = h;
         FusedArgs a{};
         a.nseg = (int)ins.size();
@@ -440,8 +491,43 @@ struct Builder {
     };
 
     // generic NHWC16 conv: out = sum over segments + bias (+temb) (+resid)
+    // A split-K conv whose first consumer is a small GroupNorm leaves its fp32 slabs un-reduced (`pend`): gn_small sums
+    // them while it reads its input (and stores the 16-bit tensor as a side product) -- one launch less per conv.
+    // Any other consumer, and any conv that would reuse the slab workspace, calls materialize() first.
+    struct Pending {
+        int slot = -1, C = 0, H = 0, W = 0, ksteps = 0, temb_off = -1, rs = -1;
+        const float *bias = nullptr;
+    } pend;
+    void materialize() {
+        if (pend.slot < 0) return;
+        bndm_unet *hh = h;
+        const Pending q = pend;
+        pend.slot = -1;
+        cur_name = S("rdce %-44s C=%-4d %dx%d", "", q.C, q.H, q.W);
+        push(OPC_OTHER, 0, [=](RunCtx &r) {
+            const int M = r.B * q.H * q.W;
+            const ConvPlan pl = plan_conv(M, q.C, q.ksteps, hh->bufs[hh->s_splitk].bytes);
+            if (pl.splitk == 1) return 0;            // the conv wrote the tensor itself
+            ConvArgs c{};
+            c.B = r.B;
+            c.H = q.H;
+            c.W = q.W;
+            c.Cout = q.C;
+            c.bias = q.bias;
+            if (q.temb_off >= 0) {
+                c.temb = r.tp_row ? r.tp_row : (const float *)hh->P(hh->s_tp);
+                c.temb_bstride = r.tp_row ? 0 : hh->ntemb;
+                c.temb_off = q.temb_off;
+            }
+            c.resid = q.rs >= 0 ? hh->P(q.rs) : nullptr;
+            c.out = hh->P(q.slot);
+            return launch_splitk_reduce(hh->dtype(), (const float *)hh->P(hh->s_splitk), pl.splitk, c, r.st);
+        });
+    }
+
     void conv(const std::vector<SegIn> &ins, const void *Wp, int Ktot, const float *bias, int temb_off,
-              const Act *resid, const Act &out, int stride, const std::string &label = "") {
+              const Act *resid, const Act &out, int stride, const std::string &label = "", bool defer = false) {
+        materialize();
         bndm_unet *hh = h;
         cur_name = S("conv %-44s K=%-5d N=%-4d %dx%d", label.c_str(), Ktot, out.C, out.H, out.W);
         ConvArgs a{};
@@ -484,6 +570,7 @@ struct Builder {
             const int nblk = ceil_div(M, 128) * ceil_div(out.C, 128);
             if (nblk < 192) h->grow(h->s_splitk, (size_t)32 * M * out.C * 4);
         }
+        const bool can_defer = defer && use_defer && use_gn_small && !h->tile_counters && stride == 1 && out.H * out.W <= 64;
         push(OPC_CONV, flops, [=](RunCtx &r) mutable {
             ConvArgs c = a;
             for (int i = 0; i < c.nseg; ++i) c.seg[i].src = hh->P(slots[i]);
@@ -497,25 +584,9 @@ struct Builder {
                 c.temb_off = 0;
             }
             const int M = r.B * c.H * c.W;
-            int tile = TILE_256x128;
-            int nblk = ceil_div(M, 256) * ceil_div(c.Cout, 128);
-            static const int big_min_m = getenv("BNDM_SPLITK_BIG_M") ? atoi(getenv("BNDM_SPLITK_BIG_M")) : (1 << 30);
-            if (nblk < 192 && M < big_min_m) {
-                tile = TILE_128x128;
-                nblk = ceil_div(M, 128) * ceil_div(c.Cout, 128);
-            }
-            int splitk = 1;
-            static const int sk_target = getenv("BNDM_SPLITK_TARGET") ? atoi(getenv("BNDM_SPLITK_TARGET")) : 256;
-            static const int sk_minsteps = getenv("BNDM_SPLITK_MINSTEPS") ? atoi(getenv("BNDM_SPLITK_MINSTEPS")) : 8;
-            if (nblk < 192 && ksteps >= 8) {
-                splitk = std::min(std::min(ceil_div(sk_target, nblk), ksteps / sk_minsteps), 32);
-                if (splitk >= 2) {
-                    const int per = ceil_div(ksteps, splitk);
-                    splitk = ceil_div(ksteps, per);          // no empty slices
-                }
-                if (splitk < 2) splitk = 1;
-            }
-            if ((size_t)splitk * M * c.Cout * 4 > hh->bufs[hh->s_splitk].bytes) splitk = 1;
+            const ConvPlan pl = plan_conv(M, c.Cout, ksteps, hh->bufs[hh->s_splitk].bytes);
+            const int tile = pl.tile, splitk = pl.splitk;
+            const int nblk = ceil_div(M, 128) * ceil_div(c.Cout, 128);
             if (splitk == 1) {
                 c.splitk = 1;
                 c.out = hh->P(so);
@@ -532,10 +603,20 @@ struct Builder {
             p.splitk = splitk;
             p.out = hh->P(hh->s_splitk);
             int e = launch_conv(hh->dtype(), tile, EPI_F32_ROWS, p, r.st);
-            if (e) return e;
+            if (e || can_defer) return e;             // deferred: the consumer (or materialize()) sums the slabs
             c.out = hh->P(so);
             return launch_splitk_reduce(hh->dtype(), (const float *)hh->P(hh->s_splitk), splitk, c, r.st);
         });
+        if (can_defer) {
+            pend.slot = out.slot;
+            pend.C = out.C;
+            pend.H = out.H;
+            pend.W = out.W;
+            pend.ksteps = ksteps;
+            pend.temb_off = temb_off;
+            pend.rs = rs;
+            pend.bias = bias;
+        }
     }
 
     const float *bias_of(const std::string &n, const std::string *plus = nullptr) {
@@ -613,7 +694,7 @@ struct Builder {
         rc = pack_conv_weight(h, {WSeg{&h->hp(name + ".conv1.weight"), Cin, 0, Cin, 9}}, Cout, 128, &W1, &K1);
         if (rc) return x1;
         Act h1 = scratch(h->s_h1, Cout, H, W);
-        conv({SegIn{y1, 9, 0}}, W1, K1, bias_of(name + ".conv1"), temb_off, nullptr, h1, 1, name + ".conv1");
+        conv({SegIn{y1, 9, 0}}, W1, K1, bias_of(name + ".conv1"), temb_off, nullptr, h1, 1, name + ".conv1", true);
         Act y2 = scratch(h->s_y2, Cout, H, W);
         group_norm(h1, nullptr, name + ".norm2", true, y2);
         if (rc) return x1;
@@ -631,11 +712,11 @@ struct Builder {
             }
             rc = pack_conv_weight(h, ws, Cout, 128, &W2, &K2);
             if (rc) return x1;
-            conv(ins, W2, K2, bias_of(name + ".conv2", &sc), -1, nullptr, out, 1, name + ".conv2+sc");
+            conv(ins, W2, K2, bias_of(name + ".conv2", &sc), -1, nullptr, out, 1, name + ".conv2+sc", true);
         } else {
             rc = pack_conv_weight(h, {WSeg{&h->hp(name + ".conv2.weight"), Cout, 0, Cout, 9}}, Cout, 128, &W2, &K2);
             if (rc) return x1;
-            conv({SegIn{y2, 9, 0}}, W2, K2, bias_of(name + ".conv2"), -1, &x1, out, 1, name + ".conv2");
+            conv({SegIn{y2, 9, 0}}, W2, K2, bias_of(name + ".conv2"), -1, &x1, out, 1, name + ".conv2", true);
         }
         return out;
     }
@@ -1034,6 +1115,7 @@ extern "C" int bndm_unet_finalize(bndm_unet *h) {
     Builder b{h};
     if (const char *e = getenv("BNDM_NO_FUSED")) b.use_fused = !(e[0] == '1');
     if (const char *e = getenv("BNDM_NO_GN_SMALL")) b.use_gn_small = !(e[0] == '1');
+    if (const char *e = getenv("BNDM_NO_DEFER")) b.use_defer = !(e[0] == '1');
     if (const char *e = getenv("BNDM_FUSED_MIN")) b.fused_min = atoi(e);
     if (const char *e = getenv("BNDM_FUSED_MAX")) b.fused_max = atoi(e);
     int rc = b.build();

@@ -593,7 +593,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_small_kernel(const T *__restrict__ x1, int C1, const T *__restrict__ x2,
                                                        int C2, int HW, int groups, float eps,
                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                       int silu, T *__restrict__ out) {
+                                                       int silu, T *__restrict__ out, const GnSlabSrc sl) {
     using v8 = typename TT<T>::v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = C1 + C2, Cb = C >> 3, CHb = Cb >> 3, RP = 256 / CHb;   // channels / 16-B chunks of this block
@@ -602,14 +602,58 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const T *__restrict__ x1,
     const int sub = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int chunk = tid % CHb, prow = tid / CHb;
     const int cl = chunk * 8, c0 = sub * Cb + cl;                 // local / global first channel of this thread
+    const bool from_slabs = sl.part != nullptr && c0 < C1;        // x1 arrives as split-K partial sums
+    if (sl.part) x1 = (const T *)sl.raw_out;
     const T *src = c0 < C1 ? x1 + (size_t)b * HW * C1 + c0 : x2 + (size_t)b * HW * C2 + (c0 - C1);
     const int Cs = c0 < C1 ? C1 : C2;
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
     if (prow < RP) {
+        f32x4 add0 = {0.f, 0.f, 0.f, 0.f}, add1 = {0.f, 0.f, 0.f, 0.f};
+        if (from_slabs) {
+            if (sl.bias) {
+                add0 = *reinterpret_cast<const f32x4 *>(sl.bias + c0);
+                add1 = *reinterpret_cast<const f32x4 *>(sl.bias + c0 + 4);
+            }
+        }
         for (int p = prow; p < HW; p += RP) {
-            const v8 v = *reinterpret_cast<const v8 *>(src + (size_t)p * Cs);
+            v8 v;
+            if (from_slabs) {
+                // same operation order as splitk_reduce_kernel: slabs in z order, + bias, + temb, + resid, round
+                const size_t m = (size_t)b * HW + p, slab = (size_t)gridDim.y * HW * C1;
+                const float *pp = sl.part + m * C1 + c0;
+                f32x4 a0 = *reinterpret_cast<const f32x4 *>(pp), a1 = *reinterpret_cast<const f32x4 *>(pp + 4);
+                for (int z = 1; z < sl.splitk; ++z) {
+                    a0 += *reinterpret_cast<const f32x4 *>(pp + (size_t)z * slab);
+                    a1 += *reinterpret_cast<const f32x4 *>(pp + (size_t)z * slab + 4);
+                }
+                if (sl.bias) {
+                    a0 += add0;
+                    a1 += add1;
+                }
+                if (sl.temb) {
+                    const float *tp = sl.temb + (size_t)b * sl.temb_bstride + sl.temb_off + c0;
+                    a0 += *reinterpret_cast<const f32x4 *>(tp);
+                    a1 += *reinterpret_cast<const f32x4 *>(tp + 4);
+                }
+                if (sl.resid) {
+                    const v8 rv = *reinterpret_cast<const v8 *>((const T *)sl.resid + m * C1 + c0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a0[e] += (float)rv[e];
+                        a1[e] += (float)rv[4 + e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = (T)a0[e];
+                    v[4 + e] = (T)a1[e];
+                }
+                *reinterpret_cast<v8 *>((T *)sl.raw_out + m * C1 + c0) = v;     // re-read below by this same thread
+            } else {
+                v = *reinterpret_cast<const v8 *>(src + (size_t)p * Cs);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float f = (float)v[e];
@@ -772,7 +816,8 @@ int launch_conv_fused(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
 }
 
 int launch_gn_small(int dtype, const void *x1, int C1, const void *x2, int C2, int B, int HW, int groups, float eps,
-                    const float *gamma, const float *beta, int silu, void *out, hipStream_t st) {
+                    const float *gamma, const float *beta, int silu, void *out, hipStream_t st, const GnSlabSrc *slab) {
+    const GnSlabSrc sl = slab ? *slab : GnSlabSrc{};
     const int C = C1 + C2;
     // a block owns C/8 channels = 4 groups; chunks of 8 channels must not straddle x1 | x2
     if (groups != 32 || C % 64 || C1 % 8 || C > 2048) {
@@ -784,10 +829,10 @@ int launch_gn_small(int dtype, const void *x1, int C1, const void *x2, int C2, i
     const dim3 grid(8, B);
     if (dtype == BNDM_DTYPE_F16)
         hipLaunchKernelGGL(gn_small_kernel<_Float16>, grid, dim3(256), smem, st, (const _Float16 *)x1, C1,
-                           (const _Float16 *)x2, C2, HW, groups, eps, gamma, beta, silu, (_Float16 *)out);
+                           (const _Float16 *)x2, C2, HW, groups, eps, gamma, beta, silu, (_Float16 *)out, sl);
     else
         hipLaunchKernelGGL(gn_small_kernel<__bf16>, grid, dim3(256), smem, st, (const __bf16 *)x1, C1,
-                           (const __bf16 *)x2, C2, HW, groups, eps, gamma, beta, silu, (__bf16 *)out);
+                           (const __bf16 *)x2, C2, HW, groups, eps, gamma, beta, silu, (__bf16 *)out, sl);
     return launch_status("gn_small");
 }
 

@@ -126,8 +126,20 @@ bool conv_tap9_supports(const FusedArgs &a);
 int launch_conv_tap9(int dtype, int TH, const FusedArgs &a, hipStream_t st);
 
 // one-launch GroupNorm(+SiLU) for small per-sample tensors (statistics + apply, one block per sample)
+// x1 given as split-K partial sums: element = round16(sum_z part[z] + bias + temb + resid); the rounded value is also
+// stored to raw_out (the tensor splitk_reduce would have produced, bit-identical)
+struct GnSlabSrc {
+    const float *part = nullptr;     // [splitk][B*HW][C1] fp32 slabs, nullptr: x1 is a plain 16-bit tensor
+    int splitk = 0;
+    const float *bias = nullptr;     // [C1]
+    const float *temb = nullptr;     // + b * temb_bstride + temb_off + c
+    int temb_bstride = 0, temb_off = 0;
+    const void *resid = nullptr;     // 16-bit [B*HW][C1]
+    void *raw_out = nullptr;         // 16-bit [B*HW][C1]
+};
 int launch_gn_small(int dtype, const void *x1, int C1, const void *x2, int C2, int B, int HW, int groups, float eps,
-                    const float *gamma, const float *beta, int silu, void *out, hipStream_t st);
+                    const float *gamma, const float *beta, int silu, void *out, hipStream_t st,
+                    const GnSlabSrc *slab = nullptr);
 
 // two-source variant of gn_finalize: statistics of cat(x1, x2) from per-tensor partial sums
 int launch_gn_finalize2(const float *p1, int nslab1, int C1, const float *p2, int nslab2, int C2, int B, int HW,
