@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F16_TFLOPS = 2500.0       # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_TRAFFIC_PER_LAUNCH = 99.0e6  # B, average over conv_fused launches (profiles/r01_pmc_traffic.txt)
+PMC_TRAFFIC_PER_LAUNCH = 131.4e6  # B, average over conv_tap9<TH=16> launches (profiles/r01_pmc_traffic.txt)
 
 
 def cpu_baseline(nb_steps, seed=0):
@@ -168,7 +168,7 @@ def main():
         _lib.check(rc, "bndm_unet_profile")
         achieved = prof.dom_flops / (prof.ms_dom * 1e-3) / 1e12
         conv_all = prof.conv_flops / (prof.ms_conv * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_fused<TH=16> (GroupNorm+SiLU fused 3x3 conv, 256-pixel tiles)",
+        roof = {"bound": "mfma", "kernel": "conv_tap9<TH=16> (GroupNorm+SiLU fused 3x3 conv, 256-pixel tiles)",
                 "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F16_TFLOPS, 4),
                 # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE
