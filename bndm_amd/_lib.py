@@ -40,6 +40,7 @@ SIGNATURES = {
     "bndm_bluenoise_workspace_bytes": (_sz, [_i, _i, _i]),
     "bndm_bluenoise": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "bndm_iadb_step": (_i, [_vp, _vp, _f, _f, _i, _i, _i, _i, _vp]),
+    "bndm_iadb_train_targets": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
     "bndm_ddim_step": (_i, [_vp, _vp, _f, _f, _f, _f, _f, _sz, _vp]),
     "bndm_export_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "bndm_unet_create": (_i, [C.POINTER(_vp), C.POINTER(UNetConfig)]),

@@ -2,6 +2,7 @@
 //   iadb_step  : utils.py:216-226 / iadb_bn.py:323-344 / latent_iadb_bn_diffusers.py:107-117
 //   ddim_step  : DDIMScheduler.step as called at ddim_diffusers.py:680
 //   export_u8  : iadb_bn.py:815-816 (truncate) / ddim_diffusers.py:687-688 (round half even)
+//   train_targets : iadb_bn.py:915,946-956 / latent_iadb_bn_diffusers.py:606-621 (forward blend + regression targets)
 #include "common.hpp"
 
 // bit-exact parity with torch's separate mul/add kernels: products and sums are written as plain
@@ -72,6 +73,46 @@ __global__ __launch_bounds__(256) void export_u8_kernel(const float *__restrict_
     }
 }
 
+// Training-time noise injection, everything after get_noise_v2: per sample b (alpha = a[b], alpha_{t-1} = ap[b])
+//   x_alpha = a*x0 + (1-a)*x1      tar1 = x1 - x0      tar2 = ap*(bn - wn)      tar = tar1 + tar2
+// in torch's evaluation order with separately rounded products (x1 is the data, x0 the noise).
+__global__ __launch_bounds__(256) void train_targets_kernel(const float *__restrict__ x0, const float *__restrict__ x1,
+                                                            const float *__restrict__ bn, const float *__restrict__ wn,
+                                                            const float *__restrict__ a, const float *__restrict__ ap,
+                                                            float *__restrict__ x_alpha, float *__restrict__ tar1,
+                                                            float *__restrict__ tar2, float *__restrict__ tar,
+                                                            size_t per4, size_t total4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / per4;
+        const float al = a[b], om = 1.0f - al;
+        const f32x4 n0 = reinterpret_cast<const f32x4 *>(x0)[i], d1 = reinterpret_cast<const f32x4 *>(x1)[i];
+        f32x4 t1, t2 = {0.f, 0.f, 0.f, 0.f};
+        if (x_alpha) {
+            f32x4 xa;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xa[e] = al * n0[e] + om * d1[e];
+            reinterpret_cast<f32x4 *>(x_alpha)[i] = xa;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t1[e] = d1[e] - n0[e];
+        if (tar1) reinterpret_cast<f32x4 *>(tar1)[i] = t1;
+        if (bn) {
+            const float apv = ap[b];
+            const f32x4 nb = reinterpret_cast<const f32x4 *>(bn)[i], nw = reinterpret_cast<const f32x4 *>(wn)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t2[e] = apv * (nb[e] - nw[e]);
+            if (tar2) reinterpret_cast<f32x4 *>(tar2)[i] = t2;
+        }
+        if (tar) {
+            f32x4 ts;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ts[e] = bn ? t1[e] + t2[e] : t1[e];
+            reinterpret_cast<f32x4 *>(tar)[i] = ts;
+        }
+    }
+}
+
 inline int grid_for(size_t n) {
     size_t b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -114,4 +155,19 @@ extern "C" int bndm_export_u8(const float *x, uint8_t *out, int B, int C, int HW
     hipLaunchKernelGGL(export_u8_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, out, C,
                        HW, rounding, total);
     return launch_status("export_u8");
+}
+
+extern "C" int bndm_iadb_train_targets(const float *x0, const float *x1, const float *noise_bn, const float *noise_wn,
+                                       const float *alpha, const float *alpha_prev, float *x_alpha, float *tar1,
+                                       float *tar2, float *tar, int B, size_t per_sample, void *stream) {
+    BNDM_REQUIRE(x0 && x1 && alpha, "bndm_iadb_train_targets: NULL tensor");
+    BNDM_REQUIRE((noise_bn == nullptr) == (noise_wn == nullptr), "bndm_iadb_train_targets: noise_bn and noise_wn go together");
+    BNDM_REQUIRE(!noise_bn || alpha_prev, "bndm_iadb_train_targets: alpha_prev is required with noise_bn / noise_wn");
+    BNDM_REQUIRE(!tar2 || noise_bn, "bndm_iadb_train_targets: tar2 needs noise_bn / noise_wn");
+    BNDM_REQUIRE(B >= 0 && per_sample % 4 == 0, "bndm_iadb_train_targets: C*H*W must be a multiple of 4");
+    const size_t per4 = per_sample / 4, total4 = per4 * (size_t)B;
+    if (total4 == 0) return 0;
+    hipLaunchKernelGGL(bndm::train_targets_kernel, dim3(bndm::grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x0,
+                       x1, noise_bn, noise_wn, alpha, alpha_prev, x_alpha, tar1, tar2, tar, per4, total4);
+    return bndm::launch_status("train_targets");
 }

@@ -142,8 +142,9 @@ class IADBScheduler(_ConfigIO):
         return x
 
     def add_noise(self, original_samples, noise, alpha):
-        a = alpha.view(-1, 1, 1, 1)
-        return (1 - a) * original_samples + a * noise
+        """(1 - alpha) * original + alpha * noise (latent_iadb_bn_diffusers.py:128-139), one HIP kernel."""
+        from .training import train_targets
+        return train_targets(noise, original_samples, None, None, alpha, None)[0]
 
     def __len__(self):
         return self.num_train_timesteps

@@ -76,6 +76,16 @@ int bndm_bluenoise(const float *L, int l_dense, const float *z, int z_layout, co
 int bndm_iadb_step(float *x, const float *d, float da, float dg, int B, int C, int Cout, int HW,
                    void *stream);
 
+/* Training-time noise injection, the arithmetic after get_noise_v2(..., 'train', inplace=False)
+ * (iadb_bn.py:881): forward blend x_alpha = alpha*x0 + (1-alpha)*x1 (iadb_bn.py:915; x1 = data, x0 = noise;
+ * IADBScheduler.add_noise, latent_iadb_bn_diffusers.py:128-133,610) and the regression targets
+ * tar1 = x1 - x0, tar2 = alpha_prev*(noise_bn - noise_wn), tar = tar1 + tar2 (iadb_bn.py:946-956,
+ * latent_iadb_bn_diffusers.py:617-620).  All tensors [B, per_sample] f32 on the device, alpha / alpha_prev [B];
+ * noise_bn == noise_wn == NULL selects the 'gaussian' / 'GBN' target (tar = tar1).  Any output may be NULL. */
+int bndm_iadb_train_targets(const float *x0, const float *x1, const float *noise_bn, const float *noise_wn,
+                            const float *alpha, const float *alpha_prev, float *x_alpha, float *tar1,
+                            float *tar2, float *tar, int B, size_t per_sample, void *stream);
+
 /* DDIMScheduler.step(...).prev_sample (ddim_diffusers.py:680): eps-prediction, eta 0,
  * x0 = clamp((x - sqrt(1-a_t) eps)/sqrt(a_t), +-clip); x' = sqrt(a_prev) x0 + sqrt(1-a_prev) eps.
  * clip <= 0 disables clipping.  In place on x. */

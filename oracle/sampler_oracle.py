@@ -156,3 +156,17 @@ def export_u8(x: torch.Tensor, rounding: str = "trunc") -> np.ndarray:
         return y.astype(np.uint8)
     y = (x / 2 + 0.5).clamp(0, 1)
     return (y.permute(0, 2, 3, 1) * 255).round().to(torch.uint8).numpy()
+
+
+def train_targets(x0, x1, noise_bn, noise_wn, alpha, alpha_prev):
+    """Training-time blend and regression targets (iadb_bn.py:915,946-956; latent_iadb_bn_diffusers.py:610,
+    617-620): x1 is the data, x0 the noise returned by get_noise_v2(..., 'train', inplace=False).
+    Returns (x_alpha, tar1, tar2, tar); tar2 is None and tar == tar1 without noise_bn / noise_wn."""
+    a = alpha.view(-1, 1, 1, 1)
+    x_alpha = a * x0 + (1 - alpha).view(-1, 1, 1, 1) * x1
+    tar1 = x1 - x0
+    if noise_bn is None:
+        return x_alpha, tar1, None, tar1.clone()
+    tar2 = alpha_prev.view(-1, 1, 1, 1) * (noise_bn - noise_wn)
+    return x_alpha, tar1, tar2, x1 - x0 + alpha_prev.view(-1, 1, 1, 1) * (noise_bn - noise_wn)
+

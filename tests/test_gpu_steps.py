@@ -70,3 +70,50 @@ def test_export_u8_bit_exact(rounding):
     out = torch.empty(3, 32, 32, 3, dtype=torch.uint8, device="cuda")
     _lib.check(lib.bndm_export_u8(_p(x.cuda()), _p(out), 3, 3, 1024, rounding, _lib.current_stream_ptr()), "export")
     assert np.array_equal(out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("two", [True, False])
+def test_train_targets_bit_exact(two):
+    """bndm_iadb_train_targets vs the oracle's torch fp32 operation order (iadb_bn.py:915,946-956)."""
+    from bndm_amd.training import train_targets
+    from oracle import sampler_oracle as S
+    g = torch.Generator().manual_seed(11)
+    B = 5
+    x0 = torch.randn(B, 3, 64, 64, generator=g)
+    x1 = torch.randn(B, 3, 64, 64, generator=g)
+    bn = torch.randn(B, 3, 64, 64, generator=g) if two else None
+    wn = torch.randn(B, 3, 64, 64, generator=g) if two else None
+    alpha = torch.rand(B, generator=g)
+    alpha_prev = torch.rand(B, generator=g) if two else None
+    ref = S.train_targets(x0, x1, bn, wn, alpha, alpha_prev)
+    dev = lambda t: None if t is None else t.cuda()
+    got = train_targets(dev(x0), dev(x1), dev(bn), dev(wn), dev(alpha), dev(alpha_prev))
+    for r, o in zip(ref, got):
+        assert (r is None) == (o is None)
+        if r is not None:
+            assert torch.equal(o.cpu(), r)
+
+
+def test_noise_injection_matches_oracle_pipeline():
+    """get_noise_v2('train', inplace=False) + blend + targets on the HIP path vs oracle noise + oracle targets on
+    the same white draw (the draw is replayed through global_z)."""
+    from bndm_amd.training import train_targets
+    from bndm_amd.bluenoise import get_noise_v2
+    from bndm_amd.synth import formula_factor
+    from oracle import noise_oracle as NO
+    from oracle import sampler_oracle as S
+    L = torch.from_numpy(formula_factor())
+    B = 3
+    g = torch.Generator().manual_seed(3)
+    x1 = torch.randn(B, 3, 64, 64, generator=g)
+    z = torch.randn(B, 3, 64, 64, generator=g)
+    gamma_t = torch.tensor([0.2, 0.5, 0.9])
+    alpha, alpha_prev = torch.tensor([0.3, 0.6, 1.0]), torch.tensor([0.29, 0.59, 0.99])
+    x0, bn, wn = get_noise_v2(torch.device("cuda"), x1.cuda(), L.cuda(), gamma_t.cuda(), None, "gaussianBN", "train",
+                              False, global_z=z.cuda())
+    rx0, rbn, rwn = NO.get_noise_v2(x1.numpy(), L.numpy(), gamma_t.numpy(), "gaussianBN", "train", z=z.numpy())
+    assert np.abs(x0.cpu().numpy() - rx0).max() <= 1e-4 * np.abs(rx0).max()
+    got = train_targets(x0, x1.cuda(), bn, wn, alpha.cuda(), alpha_prev.cuda())
+    ref = S.train_targets(x0.cpu(), x1, bn.cpu(), wn.cpu(), alpha, alpha_prev)
+    for r, o in zip(ref, got):
+        assert torch.equal(o.cpu(), r)

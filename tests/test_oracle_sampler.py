@@ -79,3 +79,42 @@ def test_export_u8():
     x = torch.tensor([-1.5, -1.0, 0.0, 0.999, 1.0, 2.0]).view(1, 1, 1, 6).repeat(1, 3, 1, 1)
     assert S.export_u8(x, "trunc")[0, 0, :, 0].tolist() == [0, 0, 127, 254, 255, 255]
     assert S.export_u8(x, "round")[0, 0, :, 0].tolist() == [0, 0, 128, 255, 255, 255]
+
+
+def test_train_targets_known_answers():
+    """iadb_bn.py:915,946-956: hand-evaluated blend and targets (x1 data, x0 noise)."""
+    x0 = torch.full((2, 1, 2, 2), 2.0)
+    x1 = torch.full((2, 1, 2, 2), -1.0)
+    bn = torch.full((2, 1, 2, 2), 0.5)
+    wn = torch.full((2, 1, 2, 2), 0.25)
+    alpha = torch.tensor([0.25, 1.0])
+    alpha_prev = torch.tensor([0.0, 0.5])
+    xa, t1, t2, t = S.train_targets(x0, x1, bn, wn, alpha, alpha_prev)
+    assert torch.equal(xa[0], torch.full((1, 2, 2), 0.25 * 2.0 + 0.75 * -1.0))
+    assert torch.equal(xa[1], torch.full((1, 2, 2), 2.0))               # alpha = 1: pure noise
+    assert torch.equal(t1, torch.full((2, 1, 2, 2), -3.0))
+    assert torch.equal(t2[0], torch.zeros(1, 2, 2)) and torch.equal(t2[1], torch.full((1, 2, 2), 0.125))
+    assert torch.equal(t, t1 + t2)
+    xa2, t1b, t2b, tb = S.train_targets(x0, x1, None, None, alpha, None)
+    assert t2b is None and torch.equal(tb, t1b) and torch.equal(xa2, xa)
+
+
+def test_train_targets_is_the_forward_of_the_sampler_step():
+    """Consistency the reference relies on (iadb_bn.py:902-911): stepping x_alpha(t) by the targets with
+    d_alpha = alpha_t - alpha_{t-1}, d_gamma = gamma_t - gamma_{t-1} lands on x_alpha(t-1) when x0 is the
+    gamma-blend of one blue and one white draw."""
+    g = torch.Generator().manual_seed(5)
+    B = 3
+    x1 = torch.randn(B, 3, 8, 8, generator=g, dtype=torch.float64)
+    bn = torch.randn(B, 3, 8, 8, generator=g, dtype=torch.float64)
+    wn = torch.randn(B, 3, 8, 8, generator=g, dtype=torch.float64)
+    a_t, a_p = torch.tensor([0.8, 0.5, 0.2], dtype=torch.float64), torch.tensor([0.7, 0.4, 0.1], dtype=torch.float64)
+    g_t, g_p = torch.tensor([0.9, 0.6, 0.3], dtype=torch.float64), torch.tensor([0.85, 0.45, 0.05], dtype=torch.float64)
+    v = lambda s: s.view(-1, 1, 1, 1)
+    x0_t = bn * (1 - v(g_t)) + wn * v(g_t)            # get_noise_recent.py:116
+    x0_p = bn * (1 - v(g_p)) + wn * v(g_p)
+    xa_t, tar1, tar2, _ = S.train_targets(x0_t, x1, bn, wn, a_t, a_p)
+    xa_p = v(a_p) * x0_p + (1 - v(a_p)) * x1
+    # exact identity: x_alpha(t-1) = x_alpha(t) + d_alpha*(x1 - x0_t) + d_gamma*alpha_{t-1}*(bn - wn)
+    stepped = xa_t + v(a_t - a_p) * tar1 + v(g_t - g_p) * tar2
+    assert torch.allclose(stepped, xa_p, atol=1e-12)
