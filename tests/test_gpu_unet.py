@@ -95,6 +95,29 @@ def test_iadb_loop_with_engine_matches_oracle_loop():
     assert _rel(snaps[0].cpu(), ref_snaps[0]) <= 2e-3
 
 
+def test_full_250_step_trajectory_psnr():
+    """SURVEY 8d end-to-end check: the BASELINE configuration's full 250-step IADB trajectory (out_channel 6,
+    sigmoid(1000,0,3) gamma, blue-noise start) on the HIP path vs the fp32 CPU oracle on identical x0 / weights:
+    PSNR of the final uint8 images >= 35 dB and bounded drift of the fp32 state."""
+    from oracle import sampler_oracle as S
+    from utils import sample_iadb
+    from bndm_amd.sampler import export_u8
+    m, U, cfg, sd = _model_and_oracle(64, 3, 6)
+    x0 = torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(9))
+    params = torch.tensor([1000.0, 0.0, 3.0])
+    torch.set_num_threads(16)
+    ref, _ = S.sample_iadb(U.OracleUNet(cfg, sd), x0, 250, "sigmoid", params, 6, "gaussianBN", "test")
+    got, _, _ = sample_iadb(m, x0.cuda(), 250, "sigmoid", params.cuda(), 6, "gaussianBN", "test")
+    u_ref = S.export_u8(ref, "trunc").astype(np.float64)
+    u_got = export_u8(got, "trunc").cpu().numpy().astype(np.float64)
+    mse = float(((u_ref - u_got) ** 2).mean())
+    psnr = 10 * np.log10(255.0 ** 2 / max(mse, 1e-12))
+    drift = float((got.cpu() - ref).abs().max())
+    print(f"250-step PSNR {psnr:.2f} dB, max |x - x_ref| {drift:.3e}, rel-L2 {_rel(got.cpu(), ref):.3e}")
+    assert psnr >= 35.0
+    assert _rel(got.cpu(), ref) <= 5e-3
+
+
 def test_generic_callable_loop_matches_reference_goldens(golden_dir):
     """sample_iadb with an arbitrary callable (analytic fake model) on the GPU vs goldens captured
     from the reference's utils.sample_iadb."""
