@@ -24,6 +24,14 @@ class UNetConfig(C.Structure):
     ]
 
 
+class VaeConfig(C.Structure):
+    _fields_ = [
+        ("latent_channels", C.c_int), ("out_channels", C.c_int), ("latent_resolution", C.c_int),
+        ("num_levels", C.c_int), ("block_out_channels", C.c_int * MAX_LEVELS),
+        ("layers_per_block", C.c_int), ("dtype", C.c_int), ("max_batch", C.c_int),
+    ]
+
+
 class UNetProfile(C.Structure):
     _fields_ = [("ms_total", C.c_float), ("ms_conv", C.c_float), ("conv_launches", C.c_int),
                 ("conv_flops", C.c_double), ("launches", C.c_int), ("ms_dom", C.c_float),
@@ -40,6 +48,8 @@ SIGNATURES = {
     "bndm_bluenoise_workspace_bytes": (_sz, [_i, _i, _i]),
     "bndm_bluenoise": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "bndm_iadb_step": (_i, [_vp, _vp, _f, _f, _i, _i, _i, _i, _vp]),
+    "bndm_vae_decoder_create": (_i, [_vp, _vp]),
+    "bndm_vae_decode": (_i, [_vp, _vp, _vp, _i, _vp]),
     "bndm_iadb_train_targets": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
     "bndm_ddim_step": (_i, [_vp, _vp, _f, _f, _f, _f, _f, _sz, _vp]),
     "bndm_export_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

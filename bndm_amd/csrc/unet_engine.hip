@@ -113,6 +113,7 @@ struct Op {
 
 struct bndm_unet {
     bndm_unet_config cfg{};
+    int kind = 0;                      // 0: UNet2DModel, 1: AutoencoderKL decoder (cfg.resolution = latent H = W)
     int temb_dim = 0;
     std::vector<ParamSpec> params;
     std::unordered_map<std::string, int> pindex;
@@ -197,6 +198,36 @@ std::string S(const char *fmt, ...) {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     return buf;
+}
+
+// AutoencoderKL decoder (+ post_quant_conv); cfg.block_out_channels holds the ENCODER order (128, 256, 512, 512)
+void build_specs_vae(bndm_unet *h) {
+    const bndm_unet_config &c = h->cfg;
+    const int n = c.num_levels, L = c.in_channels;
+    SpecBuilder sb{h};
+    auto resnet = [&](const std::string &nm, int ci, int co) {
+        sb.norm(nm + ".norm1", ci);
+        sb.conv(nm + ".conv1", ci, co, 3);
+        sb.norm(nm + ".norm2", co);
+        sb.conv(nm + ".conv2", co, co, 3);
+        if (ci != co) sb.conv(nm + ".conv_shortcut", ci, co, 1);
+    };
+    const int top = c.block_out_channels[n - 1];
+    sb.conv("post_quant_conv", L, L, 1);
+    sb.conv("decoder.conv_in", L, top, 3);
+    resnet("decoder.mid_block.resnets.0", top, top);
+    sb.attn("decoder.mid_block.attentions.0", top);
+    resnet("decoder.mid_block.resnets.1", top, top);
+    int prev = top;
+    for (int i = 0; i < n; ++i) {
+        const int oc = c.block_out_channels[n - 1 - i];
+        for (int j = 0; j < c.layers_per_block + 1; ++j)
+            resnet(S("decoder.up_blocks.%d.resnets.%d", i, j), j == 0 ? prev : oc, oc);
+        if (i != n - 1) sb.conv(S("decoder.up_blocks.%d.upsamplers.0.conv", i), oc, oc, 3);
+        prev = oc;
+    }
+    sb.norm("decoder.conv_norm_out", c.block_out_channels[0]);
+    sb.conv("decoder.conv_out", c.block_out_channels[0], c.out_channels, 3);
 }
 
 void build_specs(bndm_unet *h) {
@@ -312,6 +343,8 @@ struct Builder {
     bool use_fused = true;
     bool use_gn_small = true;
     bool use_defer = true;                 // split-K slabs summed by the consuming gn_small
+    float gn_eps = GN_EPS;                 // 1e-5 (UNet2DModel), 1e-6 (AutoencoderKL)
+    bool has_temb = true;                  // ResnetBlock2D with a time_emb_proj (UNet) or without (VAE)
     int fused_min = 16, fused_max = 1 << 20;   // resolutions (H) handled by the fused conv path
     std::unordered_map<int, StatRef> stats_of;   // activation slot -> cached GroupNorm partial sums
     std::vector<float> tp_w, tp_b;      // concatenated time_emb_proj [ntemb][temb_dim], [ntemb]
@@ -362,10 +395,11 @@ struct Builder {
         if ((rc = upload_f32(h, h->hp(pname + ".bias"), &beta))) return;
         h->grow(h->s_ss, (size_t)h->cfg.max_batch * 2 * C * 4);
         cur_name = S("gnfn %-44s C=%-4d %dx%d", pname.c_str(), C, x1.H, x1.W);
+        const float eps_ = gn_eps;
         push(OPC_OTHER, 0, [=](RunCtx &r) {
             return launch_gn_finalize2((const float *)hh->P(a1.pslot), a1.nslab, C1,
                                        a2.pslot >= 0 ? (const float *)hh->P(a2.pslot) : nullptr, a2.nslab, C2, r.B, HW,
-                                       GROUPS, GN_EPS, gamma, beta, (float *)hh->P(hh->s_ss), r.st);
+                                       GROUPS, eps_, gamma, beta, (float *)hh->P(hh->s_ss), r.st);
         });
     }
 
@@ -384,6 +418,7 @@ struct Builder {
             if (fused_reduce) pend.slot = -1;
             else materialize();
             cur_name = S("gnsm %-44s C=%-4d %dx%d", pname.c_str(), C1 + C2, x1.H, x1.W);
+            const float eps_ = gn_eps;
             push(OPC_OTHER, 0, [=](RunCtx &r) {
                 GnSlabSrc sl;
                 if (fused_reduce) {
@@ -402,7 +437,7 @@ struct Builder {
                     }
                 }
                 return launch_gn_small(hh->dtype(), hh->P(s1), C1, s2 >= 0 ? hh->P(s2) : nullptr, C2, r.B, HW, GROUPS,
-                                       GN_EPS, gamma, beta, silu ? 1 : 0, hh->P(so), r.st, sl.part ? &sl : nullptr);
+                                       eps_, gamma, beta, silu ? 1 : 0, hh->P(so), r.st, sl.part ? &sl : nullptr);
             });
             return;
         }
@@ -634,8 +669,8 @@ struct Builder {
     Act resnet(const Act &x1, const Act *x2, int Cout, const std::string &name) {
         const int C1 = x1.C, C2 = x2 ? x2->C : 0, Cin = C1 + C2, H = x1.H, W = x1.W;
         // time_emb_proj rows appended to the shared projection matrix
-        const int temb_off = temb_cursor;
-        {
+        const int temb_off = has_temb ? temb_cursor : -1;
+        if (has_temb) {
             const std::vector<float> &w = h->hp(name + ".time_emb_proj.weight");
             const std::vector<float> &b = h->hp(name + ".time_emb_proj.bias");
             tp_w.insert(tp_w.end(), w.begin(), w.end());
@@ -758,6 +793,81 @@ struct Builder {
         return out;
     }
 
+    // AutoencoderKL mid-block attention: ONE head of dim C over T = H*W tokens (4096 at a 64x64 latent).  Built from
+    // the GEMM kernel: q, k projections; V^T = Wv . yn_b^T (the projection computed transposed, its bias added after
+    // P.V because softmax rows sum to 1); S = q_b . k_b^T; row softmax in place; O = P . V; output projection + x.
+    Act attention_big(const Act &x, const std::string &name) {
+        bndm_unet *hh = h;
+        const int C = x.C, H = x.H, W = x.W, T = H * W, MB = h->cfg.max_batch;
+        if ((C & (C - 1)) || C < 128 || T % 128 || T > 4096) {
+            set_error("attention_big: C=%d T=%d unsupported (C a power of two >= 128, T a multiple of 128 <= 4096)", C, T);
+            rc = BNDM_E_ARG;
+            return x;
+        }
+        Act yn = scratch(h->s_y, C, H, W);
+        group_norm(x, nullptr, name + ".group_norm", false, yn);
+        if (rc) return x;
+        const void *Wq, *Wk, *Wo, *Wv;
+        int K;
+        if ((rc = pack_conv_weight(h, {WSeg{&h->hp(name + ".to_q.weight"), C, 0, C, 1}}, C, 128, &Wq, &K))) return x;
+        if ((rc = pack_conv_weight(h, {WSeg{&h->hp(name + ".to_k.weight"), C, 0, C, 1}}, C, 128, &Wk, &K))) return x;
+        if ((rc = pack_conv_weight(h, {WSeg{&h->hp(name + ".to_out.0.weight"), C, 0, C, 1}}, C, 128, &Wo, &K))) return x;
+        if ((rc = upload_16(h, h->hp(name + ".to_v.weight"), &Wv))) return x;       // [C out][C in]: the A operand of V^T
+        const float *bqd = bias_of(name + ".to_q"), *bkd = bias_of(name + ".to_k"), *bvd = bias_of(name + ".to_v");
+        if (rc) return x;
+        Act q = Act{h->new_slot(act_bytes(C, H, W)), C, H, W}, k = Act{h->new_slot(act_bytes(C, H, W)), C, H, W};
+        conv({SegIn{yn, 1, 0}}, Wq, K, bqd, -1, nullptr, q, 1, name + ".to_q");
+        conv({SegIn{yn, 1, 0}}, Wk, K, bkd, -1, nullptr, k, 1, name + ".to_k");
+        if (rc) return x;
+        materialize();
+        const int s_vt = h->new_slot((size_t)C * T * 2), s_p = h->new_slot((size_t)T * T * 2);
+        Act att = Act{h->new_slot(act_bytes(C, H, W)), C, H, W};
+        const int sq = q.slot, sk = k.slot, sy = yn.slot, sa = att.slot;
+        int vh = 1, vw = C;                            // V^T rows (= channels) viewed as a vh x vw "image"
+        while (vh < vw) {
+            vh <<= 1;
+            vw >>= 1;
+        }
+        (void)MB;
+        cur_name = S("attn %s T=%d C=%d", name.c_str(), T, C);
+        push(OPC_CONV, 2.0 * T * C * C + 2.0 * 2 * T * (double)T * C, [=](RunCtx &r) {
+            auto gemm = [&](const void *A, int Ah, int Aw, int Kd, const void *Wt, int N, const float *bias, void *out) {
+                ConvArgs c{};
+                c.nseg = 1;
+                c.seg[0].src = A;
+                c.seg[0].C = Kd;
+                c.seg[0].taps = 1;
+                c.seg[0].up = 0;
+                c.Wgt = Wt;
+                c.bias = bias;
+                c.H = Ah;
+                c.W = Aw;
+                c.stride = 1;
+                c.Cout = N;
+                c.Ktot = Kd;
+                c.zeros = hh->zeros;
+                c.B = 1;
+                c.splitk = 1;
+                c.out = out;
+                return launch_conv(hh->dtype(), Ah * Aw >= 2048 ? TILE_256x128 : TILE_128x128, EPI_NHWC16, c, r.st);
+            };
+            const size_t per = (size_t)T * C * 2;
+            for (int b = 0; b < r.B; ++b) {
+                const char *qb = (const char *)hh->P(sq) + b * per, *kb = (const char *)hh->P(sk) + b * per;
+                const char *yb = (const char *)hh->P(sy) + b * per;
+                int e;
+                if ((e = gemm(Wv, vh, vw, C, yb, T, nullptr, hh->P(s_vt)))) return e;               // V^T  [C][T]
+                if ((e = gemm(qb, H, W, C, kb, T, nullptr, hh->P(s_p)))) return e;                  // S    [T][T]
+                if ((e = launch_softmax_rows(hh->dtype(), hh->P(s_p), T, T, 1.0f / sqrtf((float)C), r.st))) return e;
+                if ((e = gemm(hh->P(s_p), H, W, T, hh->P(s_vt), C, bvd, (char *)hh->P(sa) + b * per))) return e;   // O
+            }
+            return 0;
+        });
+        Act out = new_act(C, H, W);
+        conv({SegIn{att, 1, 0}}, Wo, K, bias_of(name + ".to_out.0"), -1, &x, out, 1, name + ".to_out");
+        return out;
+    }
+
     Act resample(const Act &x, const std::string &name, bool down) {
         const void *Wp;
         int K;
@@ -770,6 +880,114 @@ struct Builder {
         }
         conv({SegIn{x, 9, down ? 0 : 1}}, Wp, K, bias_of(name), -1, nullptr, out, down ? 2 : 1, name);
         return out;
+    }
+
+    // AutoencoderKL.decode: post_quant_conv -> Decoder (conv_in, mid block, up blocks, GN + SiLU + conv_out)
+    int build_vae() {
+        bndm_unet *hh = h;
+        const bndm_unet_config &c = h->cfg;
+        const int n = c.num_levels, R = c.resolution, L = c.in_channels, top = c.block_out_channels[n - 1];
+        const int MB = c.max_batch;
+        has_temb = false;
+        gn_eps = 1e-6f;
+        h->s_y = h->new_slot(0);
+        h->s_h1 = h->new_slot(0);
+        h->s_y2 = h->new_slot(0);
+        h->s_part = h->new_slot(0);
+        h->s_ss = h->new_slot(0);
+        h->s_qkv = h->new_slot(0);
+        h->s_att = h->new_slot(0);
+        h->s_splitk = h->new_slot((size_t)64 << 20);
+        h->s_tp = h->new_slot(0);
+        h->s_d = h->new_slot((size_t)MB * L * R * R * 4);          // post_quant_conv output, fp32 NCHW
+        {
+            void *z;
+            std::vector<char> zz(256, 0);
+            if ((rc = upload(h, zz.data(), zz.size(), &z))) return rc;
+            h->zeros = z;
+        }
+        {
+            const float *wq, *bq;
+            if ((rc = upload_f32(h, h->hp("post_quant_conv.weight"), &wq))) return rc;
+            if ((rc = upload_f32(h, h->hp("post_quant_conv.bias"), &bq))) return rc;
+            cur_name = "post_quant_conv";
+            push(OPC_OTHER, 0, [=](RunCtx &r) {
+                return launch_pointwise_f32(r.sample, wq, bq, (float *)hh->P(hh->s_d), r.B, L, L, R * R, r.st);
+            });
+        }
+        Act x = new_act(top, R, R);
+        {
+            const int KP = ceil_div(9 * L, 16) * 16;
+            const std::vector<float> &w = h->hp("decoder.conv_in.weight");
+            std::vector<float> wp((size_t)top * KP, 0.f);
+            for (int co = 0; co < top; ++co)
+                for (int k = 0; k < 9 * L; ++k) wp[(size_t)co * KP + k] = w[(size_t)co * 9 * L + k];
+            const void *dW;
+            if ((rc = upload_16(h, wp, &dW))) return rc;
+            const float *db = bias_of("decoder.conv_in");
+            if (rc) return rc;
+            const int so = x.slot;
+            const int sst = new_stats(x, R * R / 128).pslot;
+            cur_name = "decoder.conv_in";
+            push(OPC_OTHER, 0, [=](RunCtx &r) {
+                return launch_conv_in(hh->dtype(), (const float *)hh->P(hh->s_d), L, nullptr, 0, dW, db, hh->P(so),
+                                      (float *)hh->P(sst), r.B, R, R, top, KP, r.st);
+            });
+        }
+        x = resnet(x, nullptr, top, "decoder.mid_block.resnets.0");
+        if (rc) return rc;
+        x = attention_big(x, "decoder.mid_block.attentions.0");
+        if (rc) return rc;
+        x = resnet(x, nullptr, top, "decoder.mid_block.resnets.1");
+        if (rc) return rc;
+        for (int i = 0; i < n; ++i) {
+            const int oc = c.block_out_channels[n - 1 - i];
+            for (int j = 0; j < c.layers_per_block + 1; ++j) {
+                x = resnet(x, nullptr, oc, S("decoder.up_blocks.%d.resnets.%d", i, j));
+                if (rc) return rc;
+            }
+            if (i != n - 1) {
+                x = resample(x, S("decoder.up_blocks.%d.upsamplers.0.conv", i), false);
+                if (rc) return rc;
+            }
+        }
+        {
+            const int C0 = x.C, RO = x.H;
+            Act y = scratch(h->s_y, C0, RO, RO);
+            group_norm(x, nullptr, "decoder.conv_norm_out", true, y);
+            if (rc) return rc;
+            const void *Wp;
+            int K;
+            rc = pack_conv_weight(h, {WSeg{&h->hp("decoder.conv_out.weight"), C0, 0, C0, 9}}, c.out_channels, 32, &Wp, &K);
+            if (rc) return rc;
+            const float *db = bias_of("decoder.conv_out");
+            if (rc) return rc;
+            ConvArgs a{};
+            a.nseg = 1;
+            a.seg[0].C = C0;
+            a.seg[0].taps = 9;
+            a.seg[0].up = 0;
+            a.Wgt = Wp;
+            a.bias = db;
+            a.H = RO;
+            a.W = RO;
+            a.stride = 1;
+            a.Cout = c.out_channels;
+            a.Ktot = K;
+            a.splitk = 1;
+            a.zeros = h->zeros;
+            const int sy = y.slot;
+            cur_name = S("conv decoder.conv_out K=%d N=%d %dx%d", K, c.out_channels, RO, RO);
+            push(OPC_CONV, 2.0 * 9 * C0 * c.out_channels * RO * RO, [=](RunCtx &r) {
+                ConvArgs cc = a;
+                cc.seg[0].src = hh->P(sy);
+                cc.B = r.B;
+                cc.out = r.out;
+                return launch_conv(hh->dtype(), TILE_128x32, EPI_NCHW32, cc, r.st);
+            });
+        }
+        materialize();
+        return rc;
     }
 
     int build() {
@@ -1068,6 +1286,58 @@ extern "C" int bndm_unet_create(bndm_unet **out, const bndm_unet_config *cfg) {
     return 0;
 }
 
+extern "C" int bndm_vae_decoder_create(bndm_unet **out, const bndm_vae_config *cfg) {
+    BNDM_REQUIRE(out && cfg, "bndm_vae_decoder_create: NULL argument");
+    BNDM_REQUIRE(cfg->num_levels >= 2 && cfg->num_levels <= BNDM_MAX_LEVELS, "bndm_vae_decoder_create: num_levels %d",
+                 cfg->num_levels);
+    BNDM_REQUIRE(cfg->dtype == BNDM_DTYPE_F16 || cfg->dtype == BNDM_DTYPE_BF16, "bndm_vae_decoder_create: dtype %d",
+                 cfg->dtype);
+    BNDM_REQUIRE(cfg->latent_resolution >= 16 && cfg->latent_resolution <= 64 &&
+                     (cfg->latent_resolution & (cfg->latent_resolution - 1)) == 0,
+                 "bndm_vae_decoder_create: latent resolution %d must be 16, 32 or 64", cfg->latent_resolution);
+    BNDM_REQUIRE(cfg->latent_channels >= 1 && cfg->latent_channels * 9 <= 64 && cfg->out_channels >= 1 &&
+                     cfg->out_channels <= 32,
+                 "bndm_vae_decoder_create: latent/out channels %d/%d unsupported", cfg->latent_channels,
+                 cfg->out_channels);
+    BNDM_REQUIRE(cfg->max_batch >= 1 && cfg->max_batch <= 8 && cfg->layers_per_block >= 1,
+                 "bndm_vae_decoder_create: max_batch %d outside [1, 8]", cfg->max_batch);
+    for (int i = 0; i < cfg->num_levels; ++i)
+        BNDM_REQUIRE(cfg->block_out_channels[i] % 128 == 0 && cfg->block_out_channels[i] <= 512,
+                     "bndm_vae_decoder_create: block_out_channels[%d]=%d must be a multiple of 128 and <= 512", i,
+                     cfg->block_out_channels[i]);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        (void)hipGetLastError();
+        set_error("bndm_vae_decoder_create: no HIP device visible (this path has no CPU fallback)");
+        return BNDM_E_NODEVICE;
+    }
+    bndm_unet *h = new (std::nothrow) bndm_unet();
+    if (!h) return BNDM_E_NOMEM;
+    h->kind = 1;
+    h->cfg.in_channels = cfg->latent_channels;
+    h->cfg.out_channels = cfg->out_channels;
+    h->cfg.resolution = cfg->latent_resolution;
+    h->cfg.num_levels = cfg->num_levels;
+    for (int i = 0; i < cfg->num_levels; ++i) h->cfg.block_out_channels[i] = cfg->block_out_channels[i];
+    h->cfg.layers_per_block = cfg->layers_per_block;
+    h->cfg.dtype = cfg->dtype;
+    h->cfg.max_batch = cfg->max_batch;
+    build_specs_vae(h);
+    h->host.resize(h->params.size());
+    h->loaded.assign(h->params.size(), 0);
+    *out = h;
+    return 0;
+}
+
+extern "C" int bndm_vae_decode(bndm_unet *h, const float *latents, float *out, int B, void *stream) {
+    int rc = check_ready(h, B, "bndm_vae_decode");
+    if (rc) return rc;
+    BNDM_REQUIRE(h->kind == 1, "bndm_vae_decode: the handle is not a VAE decoder");
+    BNDM_REQUIRE(latents && out, "bndm_vae_decode: NULL tensor");
+    RunCtx r{B, (hipStream_t)stream, latents, nullptr, nullptr, out};
+    return run_forward(h, r);
+}
+
 extern "C" void bndm_unet_destroy(bndm_unet *h) {
     if (!h) return;
     for (void *p : h->weights) (void)hipFree(p);
@@ -1118,7 +1388,7 @@ extern "C" int bndm_unet_finalize(bndm_unet *h) {
     if (const char *e = getenv("BNDM_NO_DEFER")) b.use_defer = !(e[0] == '1');
     if (const char *e = getenv("BNDM_FUSED_MIN")) b.fused_min = atoi(e);
     if (const char *e = getenv("BNDM_FUSED_MAX")) b.fused_max = atoi(e);
-    int rc = b.build();
+    int rc = h->kind == 1 ? b.build_vae() : b.build();
     if (rc) return rc;
     for (Buf &bf : h->bufs) {
         BNDM_CHECK_HIP(hipMalloc(&bf.ptr, bf.bytes ? bf.bytes : 16));
@@ -1133,6 +1403,7 @@ extern "C" int bndm_unet_forward(bndm_unet *h, const float *sample, const float 
                                  void *stream) {
     int rc = check_ready(h, B, "bndm_unet_forward");
     if (rc) return rc;
+    BNDM_REQUIRE(h->kind == 0, "bndm_unet_forward: the handle is a VAE decoder");
     BNDM_REQUIRE(sample && timesteps && out, "bndm_unet_forward: NULL tensor");
     RunCtx r{B, (hipStream_t)stream, sample, nullptr, timesteps, out};
     return run_forward(h, r);
@@ -1143,6 +1414,7 @@ extern "C" int bndm_unet_sample_iadb(bndm_unet *h, float *x, const float *extra_
                                      const uint8_t *snap_mask, float *snapshots, void *stream) {
     int rc = check_ready(h, B, "bndm_unet_sample_iadb");
     if (rc) return rc;
+    BNDM_REQUIRE(h->kind == 0, "bndm_unet_sample_iadb: the handle is a VAE decoder");
     BNDM_REQUIRE(x && t_in && da && dg && nb_step >= 0, "bndm_unet_sample_iadb: NULL table");
     const int Cin = h->cfg.in_channels, Cout = h->cfg.out_channels, R = h->cfg.resolution;
     BNDM_REQUIRE((extra_in ? 2 * C : C) == Cin, "bndm_unet_sample_iadb: x has %d channels, model takes %d%s", C, Cin,

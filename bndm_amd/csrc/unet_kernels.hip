@@ -815,8 +815,8 @@ int launch_splitk_reduce(int dtype, const float *part, int splitk, const ConvArg
 int launch_conv_in(int dtype, const float *x, int Cx, const float *extra, int Ce, const void *W16, const float *bias,
                    void *out, float *stats, int B, int H, int W, int C0, int KP, hipStream_t st) {
     const int M = B * H * W;
-    if ((H * W) % 128 || (C0 != 64 && C0 != 128 && C0 != 256)) {
-        set_error("conv_in: H*W=%d must be a multiple of 128 and C0=%d one of 64/128/256", H * W, C0);
+    if ((H * W) % 128 || (C0 != 64 && C0 != 128 && C0 != 256 && C0 != 512)) {
+        set_error("conv_in: H*W=%d must be a multiple of 128 and C0=%d one of 64/128/256/512", H * W, C0);
         return BNDM_E_ARG;
     }
     const int blocks = M / 128;
@@ -824,6 +824,16 @@ int launch_conv_in(int dtype, const float *x, int Cx, const float *extra, int Ce
     const int patch_bytes = (Cx + Ce) * rows * cols * 2;
     const int tile_bytes = 128 * C0 * 2 + (256 / (C0 / 8)) * C0 * 2 * 4;
     const int smem = patch_bytes > tile_bytes ? patch_bytes : tile_bytes;
+    if (smem > 64 * 1024) {
+        static bool attr = false;
+        if (!attr) {
+            BNDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_in_kernel<_Float16>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            BNDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_in_kernel<__bf16>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
+    }
     if (dtype == BNDM_DTYPE_F16)
         hipLaunchKernelGGL(conv_in_kernel<_Float16>, dim3(blocks), dim3(256), smem, st, x, Cx, extra, Ce,
                            (const _Float16 *)W16, bias, (_Float16 *)out, stats, B, ilog2(H), ilog2(W), C0, KP);
@@ -831,6 +841,89 @@ int launch_conv_in(int dtype, const float *x, int Cx, const float *extra, int Ce
         hipLaunchKernelGGL(conv_in_kernel<__bf16>, dim3(blocks), dim3(256), smem, st, x, Cx, extra, Ce,
                            (const __bf16 *)W16, bias, (__bf16 *)out, stats, B, ilog2(H), ilog2(W), C0, KP);
     return launch_status("conv_in");
+}
+
+namespace {
+// one wave per row; lane l owns the 16-byte chunks l, l+64, ... of the row (at most 8 of them)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(T *__restrict__ s, int rows, int n, float scale) {
+    using v8 = typename TT<T>::v8;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (row >= rows) return;
+    T *p = s + (size_t)row * n;
+    const int nch = n >> 3;
+    float v[8][8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = l + 64 * i;
+        if (c < nch) {
+            const v8 x = *reinterpret_cast<const v8 *>(p + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[i][e] = (float)x[e] * scale;
+                mx = fmaxf(mx, v[i][e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (l + 64 * i < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[i][e] = __expf(v[i][e] - mx);
+                sum += v[i][e];
+            }
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = l + 64 * i;
+        if (c < nch) {
+            v8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (T)(v[i][e] * inv);
+            *reinterpret_cast<v8 *>(p + c * 8) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pointwise_f32_kernel(const float *__restrict__ z, const float *__restrict__ w,
+                                                            const float *__restrict__ bias, float *__restrict__ out,
+                                                            int Cin, int Cout, int HW, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW);
+        const size_t bm = i / HW;
+        const int m = (int)(bm % Cout);
+        const size_t b = bm / Cout;
+        float acc = bias[m];
+        for (int c = 0; c < Cin; ++c) acc += w[m * Cin + c] * z[(b * Cin + c) * HW + p];
+        out[i] = acc;
+    }
+}
+}  // namespace
+
+int launch_softmax_rows(int dtype, void *s, int rows, int n, float scale, hipStream_t st) {
+    if (n % 8 || n > 4096 || rows < 1) {
+        set_error("softmax_rows: row length %d unsupported (multiple of 8, <= 4096)", n);
+        return BNDM_E_ARG;
+    }
+    const dim3 grid((rows + 3) / 4);
+    if (dtype == BNDM_DTYPE_F16) hipLaunchKernelGGL(softmax_rows_kernel<_Float16>, grid, dim3(256), 0, st, (_Float16 *)s, rows, n, scale);
+    else hipLaunchKernelGGL(softmax_rows_kernel<__bf16>, grid, dim3(256), 0, st, (__bf16 *)s, rows, n, scale);
+    return launch_status("softmax_rows");
+}
+
+int launch_pointwise_f32(const float *z, const float *w, const float *bias, float *out, int B, int Cin, int Cout, int HW,
+                         hipStream_t st) {
+    const size_t total = (size_t)B * Cout * HW;
+    hipLaunchKernelGGL(pointwise_f32_kernel, dim3(grid_for(total)), dim3(256), 0, st, z, w, bias, out, Cin, Cout, HW, total);
+    return launch_status("pointwise_f32");
 }
 
 // Host: per-K-step table of the FAST addressing path (4 ints per step)

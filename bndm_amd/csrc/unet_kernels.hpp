@@ -68,6 +68,11 @@ int launch_gn_apply(int dtype, const void *x1, int C1, const void *x2, int C2, c
 
 // softmax(q k^T / sqrt(8)) v per (sample, head of 8 channels); qkv [B*T][3C] -> out [B*T][C]
 int launch_attention(int dtype, const void *qkv, void *out, int B, int T, int C, hipStream_t st);
+// in-place row softmax of a 16-bit [rows][n] matrix: p = softmax(scale * s) with fp32 maths (n % 8 == 0, n <= 4096)
+int launch_softmax_rows(int dtype, void *s, int rows, int n, float scale, hipStream_t st);
+// 1x1 conv on a tiny fp32 NCHW tensor (AutoencoderKL.post_quant_conv): out[b][m][p] = bias[m] + sum_c w[m][c]*z[b][c][p]
+int launch_pointwise_f32(const float *z, const float *w, const float *bias, float *out, int B, int Cin, int Cout, int HW,
+                         hipStream_t st);
 
 // Timesteps(128, flip_sin_to_cos) -> Linear -> SiLU -> Linear -> SiLU, fp32; writes 16-bit [B][D]
 int launch_temb_mlp(int dtype, const float *t, int B, int C0, int D, const float *W1t /*[C0][D]*/, const float *b1,

@@ -170,6 +170,28 @@ typedef struct bndm_unet_profile_t {
 int  bndm_unet_profile(bndm_unet *h, const float *sample, const float *timesteps, float *out, int B,
                        int iters, bndm_unet_profile_t *prof, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * AutoencoderKL decoder: vae.decode((x / 0.18215).half()).sample as called at
+ * latent_iadb_bn_diffusers.py:185-191,531-533 (vae = AutoencoderKL.from_pretrained("stabilityai/sd-vae-ft-mse"),
+ * :70-71).  The handle is the same opaque type as the UNet's: bndm_unet_num_params / param_info / load_param /
+ * finalize / destroy apply; state-dict keys are diffusers' ("post_quant_conv.*", "decoder.*").
+ * ------------------------------------------------------------------------------------------ */
+typedef struct bndm_vae_config {
+    int latent_channels;                         /* 4                                              */
+    int out_channels;                            /* 3                                              */
+    int latent_resolution;                       /* H == W of the latent: 16, 32 or 64             */
+    int num_levels;                              /* len(block_out_channels)                        */
+    int block_out_channels[BNDM_MAX_LEVELS];     /* encoder order, (128, 256, 512, 512)            */
+    int layers_per_block;                        /* 2 (the decoder runs layers_per_block + 1)      */
+    int dtype;                                   /* BNDM_DTYPE_F16 / BNDM_DTYPE_BF16               */
+    int max_batch;                               /* <= 8                                           */
+} bndm_vae_config;
+
+int  bndm_vae_decoder_create(bndm_unet **out, const bndm_vae_config *cfg);
+/* latents [B, latent_channels, r, r] f32 (device), ALREADY divided by the scaling factor;
+ * out [B, out_channels, r << (num_levels-1), same] f32 (device) */
+int  bndm_vae_decode(bndm_unet *h, const float *latents, float *out, int B, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
