@@ -4,9 +4,11 @@ of the reference's latent IADB script (latent_iadb_bn_diffusers.py:472-574; BNDM
 
 The latent loop (4-channel 64x64 latents, UNet 4 -> 4 or 4 -> 8, gamma == alpha linear,
 :84-122,:524-529) runs inside the HIP engine.  The reference then decodes with the
-``stabilityai/sd-vae-ft-mse`` VAE fetched from the HF hub (:70,:185-191); the hub is unreachable here and
-the VAE decoder is SURVEY.md section 8f item f1 (next), so this build writes the final latents
-(``<output_dir>/latents/<name>_<idx>.npy``) and a 3-channel preview PNG instead of decoded images.
+``stabilityai/sd-vae-ft-mse`` VAE fetched from the HF hub (:70,:185-191,:531-540).  The hub is unreachable here:
+``--vae_dir`` takes a local directory in diffusers layout (config.json + diffusion_pytorch_model.safetensors);
+without it the decoder (bndm_amd/vae.py, HIP) runs with seeded random-init weights, which exercises the whole
+path but does not produce pictures.  Outputs: ``<output_dir>/images/<name>_<idx>.png`` as the reference writes them
+(:540,:566), plus the final latents ``<output_dir>/latents/<name>_<idx>.npy``.
 """
 from __future__ import annotations
 
@@ -51,6 +53,8 @@ def build_parser():
     g.add_argument("--full_batches", action="store_true", help="sample every latent of every batch")
     g.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     g.add_argument("--root", default=".")
+    g.add_argument("--vae_dir", default=None, help="local AutoencoderKL directory (diffusers layout)")
+    g.add_argument("--no_decode", action="store_true", help="write latents only")
     return p
 
 
@@ -97,11 +101,22 @@ def main(argv=None):
                             up_block_types=tuple("AttnUpBlock2D" if i == au else "UpBlock2D" for i in range(n)),
                             dtype=args.dtype, seed=args.seed)
     model = model.to(device).eval()
-    say("[bndm] VAE decode (stabilityai/sd-vae-ft-mse from the HF hub) is unavailable offline: writing latents + previews")
+    vae = None
+    lat = args.resolution // 8
+    if not args.no_decode and lat in (16, 32, 64):
+        from .vae import AutoencoderKL, vae_decode
+        if args.vae_dir:
+            vae = AutoencoderKL.from_pretrained(args.vae_dir, dtype=args.dtype)
+        else:
+            say("[bndm] no --vae_dir (stabilityai/sd-vae-ft-mse lives on the HF hub): decoding with seeded random-init "
+                "VAE weights")
+            vae = AutoencoderKL(dtype=args.dtype, seed=args.seed)
+        vae = vae.to(device).eval()
+    else:
+        say("[bndm] VAE decode skipped: writing latents + previews")
     name = {"gaussian": "iadb_gwn", "gaussianBN": "iadb_gwn2gbn"}.get(args.noise_type)
     if name is None:
         raise ValueError(f"Unsupported noise type: {args.noise_type}")
-    lat = args.resolution // 8
     cnt = 0
     for i in range(args.test_samples // args.eval_batch_size):
         noise = np.random.randn(args.eval_batch_size, 4, lat, lat).astype(np.float32)       # white x0 (:502)
@@ -117,11 +132,18 @@ def main(argv=None):
         if bc == 0:
             continue
         x = scheduler.sample(model, torch.from_numpy(noise[b0:b0 + bc]).to(device))        # loop of :524-529
-        z = (x / 0.18215).cpu().numpy()                                                    # what vae.decode would get (:186)
+        z = (x / 0.18215).cpu().numpy()                                                    # what vae.decode gets (:186)
+        images = None
+        if vae is not None:
+            from .sampler import export_u8
+            images = export_u8(vae_decode(vae, x), "round").cpu().numpy()                  # :539-540
+        from PIL import Image
         for j in range(bc):
             idx = cnt + b0 + j + 1
             np.save(os.path.join(out_dir, "latents", f"{name}_{idx:05d}.npy"), z[j])
-            from PIL import Image
+            if images is not None:
+                Image.fromarray(images[j]).save(os.path.join(out_dir, "images", f"{name}_{idx:05d}.png"))   # :566
+                continue
             pv = z[j, :3]
             pv = (pv - pv.min()) / max(pv.max() - pv.min(), 1e-8)
             Image.fromarray((pv.transpose(1, 2, 0) * 255).astype(np.uint8)).save(

@@ -214,5 +214,5 @@ class AutoencoderKL(nn.Module):
 
 
 def vae_decode(vae, x):
-    """latent_iadb_bn_diffusers.py:185-191: ``vae.decode((x / 0.18215).half()).sample``."""
-    return vae.decode((x / vae.config["scaling_factor"]).half()).sample
+    """latent_iadb_bn_diffusers.py:185-191: ``latents = 1 / 0.18215 * latents; vae.decode(latents.half()).sample``."""
+    return vae.decode((1 / vae.config["scaling_factor"] * x).half()).sample

@@ -171,9 +171,9 @@ def decode(sd, cfg, z: torch.Tensor) -> torch.Tensor:
 
 
 def vae_decode(sd, cfg, x: torch.Tensor) -> torch.Tensor:
-    """latent_iadb_bn_diffusers.py:185-191: decode(x / 0.18215) (the reference's .half() cast is the product path's
-    16-bit storage; the oracle stays in fp32)."""
-    return decode(sd, cfg, x / SCALING)
+    """latent_iadb_bn_diffusers.py:185-191: decode(1 / 0.18215 * x) (the reference's .half() cast is the product
+    path's 16-bit storage; the oracle stays in fp32)."""
+    return decode(sd, cfg, 1 / SCALING * x)
 
 
 def flops_per_image(cfg, latent_res: int) -> float:

@@ -49,6 +49,11 @@ def test_ddim_latent_and_superres_cli(workdir):
                    f"--ddpm_num_inference_steps=3 --full_batches --root={workdir}").split()) == 0
     lat = glob.glob(os.path.join(workdir, "results_gaussianBN", "latent_iadb_cat_res512_gaussianBN", "latents", "*.npy"))
     assert len(lat) == 2 and np.load(lat[0]).shape == (4, 64, 64)
+    pngs = sorted(glob.glob(os.path.join(workdir, "results_gaussianBN", "latent_iadb_cat_res512_gaussianBN", "images",
+                                         "iadb_gwn2gbn_*.png")))
+    assert [os.path.basename(p) for p in pngs] == ["iadb_gwn2gbn_00001.png", "iadb_gwn2gbn_00002.png"]   # :566
+    from PIL import Image
+    assert Image.open(pngs[0]).size == (512, 512)                      # decoded by the HIP AutoencoderKL decoder
     os.chdir(os.path.dirname(workdir))
     assert iadb(("--dataset=church_res128 --res=128 --batch_size=1 --train_or_test=test --nb_steps=3 --test_samples=2 "
                  "--is_conditional --noise_type=gaussianBN --scheduler_gamma=sigmoid --scheduler_param=0.2 "
