@@ -557,11 +557,19 @@ __global__ __launch_bounds__(128) void gn_finalize2_kernel(const float *__restri
         const float *p;
         int ns, Cs, cc;
         if (c < C1) { p = p1; ns = nslab1; Cs = C1; cc = c; } else { p = p2; ns = nslab2; Cs = C2; cc = c - C1; }
+        // loads in batches of 8 (independent, in flight together); the sums keep the slab order
         float s = 0, q = 0;
-        for (int k = 0; k < ns; ++k) {
-            const float2 v = *reinterpret_cast<const float2 *>(p + ((size_t)(b * ns + k) * Cs + cc) * 2);
-            s += v.x;
-            q += v.y;
+        for (int k0 = 0; k0 < ns; k0 += 8) {
+            float2 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k0 + k < ns) v[k] = *reinterpret_cast<const float2 *>(p + ((size_t)(b * ns + k0 + k) * Cs + cc) * 2);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k0 + k < ns) {
+                    s += v[k].x;
+                    q += v[k].y;
+                }
         }
         cs[cl] = s;
         css[cl] = q;
@@ -624,9 +632,20 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const T *__restrict__ x1,
                 const size_t m = (size_t)b * HW + p, slab = (size_t)gridDim.y * HW * C1;
                 const float *pp = sl.part + m * C1 + c0;
                 f32x4 a0 = *reinterpret_cast<const f32x4 *>(pp), a1 = *reinterpret_cast<const f32x4 *>(pp + 4);
-                for (int z = 1; z < sl.splitk; ++z) {
-                    a0 += *reinterpret_cast<const f32x4 *>(pp + (size_t)z * slab);
-                    a1 += *reinterpret_cast<const f32x4 *>(pp + (size_t)z * slab + 4);
+                for (int z0 = 1; z0 < sl.splitk; z0 += 4) {        // four slabs in flight; sums stay in z order
+                    f32x4 u0[4], u1[4];
+#pragma unroll
+                    for (int z = 0; z < 4; ++z)
+                        if (z0 + z < sl.splitk) {
+                            u0[z] = *reinterpret_cast<const f32x4 *>(pp + (size_t)(z0 + z) * slab);
+                            u1[z] = *reinterpret_cast<const f32x4 *>(pp + (size_t)(z0 + z) * slab + 4);
+                        }
+#pragma unroll
+                    for (int z = 0; z < 4; ++z)
+                        if (z0 + z < sl.splitk) {
+                            a0 += u0[z];
+                            a1 += u1[z];
+                        }
                 }
                 if (sl.bias) {
                     a0 += add0;

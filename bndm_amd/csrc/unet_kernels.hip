@@ -385,9 +385,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
         const size_t m = i / C4;
         const int co = (int)(i - m * C4) * 4;
         f32x4 s = *reinterpret_cast<const f32x4 *>(part + m * a.Cout + co);
-        for (int z = 1; z < splitk; ++z) {
-            const f32x4 p = *reinterpret_cast<const f32x4 *>(part + ((size_t)z * M + m) * a.Cout + co);
-            s += p;
+        for (int z0 = 1; z0 < splitk; z0 += 8) {                 // eight slabs in flight; sums stay in z order
+            f32x4 u[8];
+#pragma unroll
+            for (int z = 0; z < 8; ++z)
+                if (z0 + z < splitk) u[z] = *reinterpret_cast<const f32x4 *>(part + ((size_t)(z0 + z) * M + m) * a.Cout + co);
+#pragma unroll
+            for (int z = 0; z < 8; ++z)
+                if (z0 + z < splitk) s += u[z];
         }
         if (a.bias) s += *reinterpret_cast<const f32x4 *>(a.bias + co);
         if (a.temb) {
