@@ -767,6 +767,12 @@ bool conv_tap9_supports(const FusedArgs &a) {
         else if ((a.seg[i].ss_off >= 0) != (a.seg[0].ss_off >= 0)) return false;   // all 3x3 segments normalised, or none
         nchunks += a.seg[i].C / 64;
     }
+    // 32-bit buffer offsets: every source tensor (and the weight panel) must stay below 2 GiB
+    for (int i = 0; i < a.nseg; ++i) {
+        const long long px = a.seg[i].up ? (long long)(a.H / 2) * (a.W / 2) : (long long)a.H * a.W;
+        if ((long long)a.B * px * a.seg[i].C * 2 >= (1LL << 31)) return false;
+    }
+    if ((long long)128 * a.Ktot * 2 >= (1LL << 31)) return false;
     return a.nseg >= 1 && a.seg[0].taps == 9 && nchunks <= TAP9_MAX_CHUNKS;
 }
 
