@@ -228,13 +228,24 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
         }
     }
     int cur = 0, nxt = STAGES - 1;
+    // profiling aid (BNDM_IGEMM_TRACE): block (0, 0) records s_memtime marks of its first 24 K-steps
+    const bool tracing = EPI != EPI_SPLITK_FUSED && a.counters != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
+    auto mark = [&](int it, int k) {
+        if (tracing && it < 24) {
+            const unsigned tm = (unsigned)__builtin_amdgcn_s_memtime();
+            if (l == 0) a.counters[(w * 24 + it) * 5 + k] = tm;
+        }
+    };
     for (int it = 0; it < nsteps; ++it) {
+        mark(it, 0);
         const int younger = issued - it - 1;           // stages in flight behind the one needed now (uniform)
         if (younger >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD * (STAGES - 2)) : "memory");
         else if (STAGES > 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        mark(it, 1);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        mark(it, 2);
         if (issued < nsteps) {
             if (FAST) {
                 stage_fast(nxt, ks_begin + issued);
@@ -244,23 +255,29 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
             }
             ++issued;
         }
+        mark(it, 3);
         const char *Xt = smem + cur * STAGE;
         const char *Wt = Xt + X_BYTES;
+        // all fragment reads of the K-step are issued up front; the MFMAs of slice s start as soon as its own
+        // reads have returned (in-order lgkmcnt) while the later slices are still in flight
+        v8 af[4][TN], bf[4][TM];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int pc = ((2 * s + kh) ^ key) * 16;
-            v8 af[TN], bf[TM];
 #pragma unroll
             for (int i = 0; i < TN; ++i)
-                af[i] = *reinterpret_cast<const v8 *>(Wt + (wn * TN * 32 + i * 32 + frow) * 128 + pc);
+                af[s][i] = *reinterpret_cast<const v8 *>(Wt + (wn * TN * 32 + i * 32 + frow) * 128 + pc);
 #pragma unroll
             for (int j = 0; j < TM; ++j)
-                bf[j] = *reinterpret_cast<const v8 *>(Xt + (wm * TM * 32 + j * 32 + frow) * 128 + pc);
+                bf[s][j] = *reinterpret_cast<const v8 *>(Xt + (wm * TM * 32 + j * 32 + frow) * 128 + pc);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TM; ++j) acc[i][j] = TT<T>::mfma(af[i], bf[j], acc[i][j]);
-        }
+                for (int j = 0; j < TM; ++j) acc[i][j] = TT<T>::mfma(af[s][i], bf[s][j], acc[i][j]);
+        mark(it, 4);
         cur = cur + 1 == STAGES ? 0 : cur + 1;
         nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
     }
@@ -749,6 +766,36 @@ int launch_conv_cfg2(const ConvArgs &a, hipStream_t st) {
         attr = true;
     }
     dim3 grid(ntm * ntn, a.splitk > 1 ? a.splitk : 1);
+    if (EPI != EPI_SPLITK_FUSED && getenv("BNDM_IGEMM_TRACE")) {
+        // profiling aid: marks of the first launch whose K-step count equals BNDM_IGEMM_TRACE_KSTEPS are dumped as text
+        static unsigned *buf = nullptr;
+        static bool done = false;
+        const int want = getenv("BNDM_IGEMM_TRACE_KSTEPS") ? atoi(getenv("BNDM_IGEMM_TRACE_KSTEPS")) : 144;
+        if (!done && ksteps == want) {
+            if (!buf) BNDM_CHECK_HIP(hipMalloc(&buf, 16 * 24 * 5 * sizeof(unsigned)));
+            BNDM_CHECK_HIP(hipMemsetAsync(buf, 0, 16 * 24 * 5 * sizeof(unsigned), st));
+            ConvArgs t = a;
+            t.counters = buf;
+            hipLaunchKernelGGL((conv_igemm<T, WM, WN, TM, TN, EPI, STAGES, FAST>), grid, dim3(WM * WN * 64), smem, st, t,
+                               ksteps, ilog2(a.W), ilog2(a.H), ntm, ntn);
+            BNDM_CHECK_HIP(hipStreamSynchronize(st));
+            unsigned hbuf[16 * 24 * 5];
+            BNDM_CHECK_HIP(hipMemcpy(hbuf, buf, sizeof(hbuf), hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(getenv("BNDM_IGEMM_TRACE"), "w")) {
+                fprintf(f, "# waves %d tile %dx%d splitk %d ksteps %d grid %d M=%d N=%d\n", WM * WN, WM * TM * 32, WN * TN * 32,
+                        a.splitk, ksteps, ntm * ntn, a.B * a.H * a.W, a.Cout);
+                for (int w = 0; w < WM * WN; ++w)
+                    for (int it = 0; it < 24; ++it) {
+                        fprintf(f, "w%d s%d", w, it);
+                        for (int k = 0; k < 5; ++k) fprintf(f, " %u", hbuf[(w * 24 + it) * 5 + k] - hbuf[0]);
+                        fprintf(f, "\n");
+                    }
+                fclose(f);
+            }
+            done = true;
+            return launch_status("conv_igemm");
+        }
+    }
     hipLaunchKernelGGL((conv_igemm<T, WM, WN, TM, TN, EPI, STAGES, FAST>), grid, dim3(WM * WN * 64), smem, st, a,
                        ksteps, ilog2(a.W), ilog2(a.H), ntm, ntn);
     return launch_status("conv_igemm");
