@@ -48,6 +48,17 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base) {
         (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+// Buffer descriptor from values that ARE wave-uniform; the readfirstlanes make that provable to the compiler,
+// which otherwise wraps every buffer instruction in a waterfall loop.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *p, int bytes) {
+    const uint64_t u = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
 __device__ __forceinline__ void wait_vmem_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -39,18 +39,7 @@ constexpr int dmas_after_round(int nround, int r, int s) {
     return n;
 }
 
-typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef uint32_t u32x4t __attribute__((ext_vector_type(4)));
-
-// Buffer descriptor from values that ARE wave-uniform; the readfirstlanes make that provable to the compiler,
-// which otherwise wraps every buffer instruction in a waterfall loop.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *p, int bytes) {
-    const uint64_t u = (uint64_t)p;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0,
-                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
 
 constexpr int TAP9_MAX_CHUNKS = 64;
 
