@@ -95,6 +95,19 @@ def test_iadb_loop_with_engine_matches_oracle_loop():
     assert _rel(snaps[0].cpu(), ref_snaps[0]) <= 2e-3
 
 
+def test_forward_is_bitwise_repeatable():
+    """Race screen for the in-kernel hand-offs (counted vmcnt waits, LDS-DMA rings, deferred split-K sums): the
+    same forward repeated must be bit-identical, and a sample's result must not depend on its batch position."""
+    m, U, cfg, sd = _model_and_oracle(64, 3, 6)
+    x = torch.randn(9, 3, 64, 64, generator=torch.Generator().manual_seed(12)).cuda()
+    t = torch.full((9,), 0.37, device="cuda")
+    ref = m(x, t, return_dict=False)[0].clone()
+    for _ in range(8):
+        assert torch.equal(m(x, t, return_dict=False)[0], ref)
+    perm = torch.tensor([3, 0, 8, 1, 2, 7, 4, 6, 5], device="cuda")
+    assert torch.equal(m(x[perm], t, return_dict=False)[0], ref[perm])
+
+
 def test_full_250_step_trajectory_psnr():
     """SURVEY 8d end-to-end check: the BASELINE configuration's full 250-step IADB trajectory (out_channel 6,
     sigmoid(1000,0,3) gamma, blue-noise start) on the HIP path vs the fp32 CPU oracle on identical x0 / weights:
