@@ -26,16 +26,19 @@ template <int N> struct IC {
     static constexpr int value = N;
 };
 
-// patch DMA rounds issued after the barrier of tap t (three per tap from tap 0 on); t is taken modulo 9
+// patch DMA rounds issued after the barrier of tap t: ceil(nround / 3) per tap over taps 0..2; t is taken modulo 9
+constexpr int rounds_per_tap(int nround) { return (nround + 2) / 3; }
 constexpr int rounds_at_tap(int nround, int t) {
     t = ((t % 9) + 9) % 9;
-    return t > 1 ? 0 : (nround - 3 * t >= 3 ? 3 : (nround - 3 * t > 0 ? nround - 3 * t : 0));
+    const int rpt = rounds_per_tap(nround), left = nround - rpt * t;
+    return t > 2 ? 0 : (left >= rpt ? rpt : (left > 0 ? left : 0));
 }
-// DMAs a thread has issued after patch round r by the end of group G_s (see the loop comment)
-constexpr int dmas_after_round(int nround, int r, int s) {
-    const int g = r / 3;
-    int n = (3 * g + 2 < nround - 1 ? 3 * g + 2 : nround - 1) - r;
-    for (int j = g + 1; j <= s; ++j) n += 2 + rounds_at_tap(nround, j);
+// DMAs a thread has issued after patch round r by the end of group G_s (see the loop comment); nwp = weight pieces
+// per thread and tile
+constexpr int dmas_after_round(int nround, int nwp, int r, int s) {
+    const int rpt = rounds_per_tap(nround), g = r / rpt;
+    int n = (rpt * g + rpt - 1 < nround - 1 ? rpt * g + rpt - 1 : nround - 1) - r;
+    for (int j = g + 1; j <= s; ++j) n += nwp + rounds_at_tap(nround, j);
     return n;
 }
 
@@ -58,22 +61,26 @@ struct Chunk {
 // ABL: profiling switches (results are wrong when non-zero): 1 no MFMA, 2 no weight DMA, 4 no fragment reads,
 // 8 no in-loop patch DMA / normalisation, 16 no in-loop normalisation (DMA kept), 64 record s_memtime marks of
 // block 0 / chunk 1 into dbg[wave][tap][6]
-template <typename T, int TH, int ABL>
-__global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int tiles_x, const int tps, const int ntn,
+// NW: waves per block.  8: 4(M) x 2(N) waves of 64x64, two per SIMD.  4: 2(M) x 2(N) waves of 128x64, one per SIMD
+// with the whole 512-register file.
+template <typename T, int TH, int ABL, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_tap9(const FusedArgs a, const int tiles_x, const int tps, const int ntn,
                                                  unsigned *__restrict__ dbg) {
     using v8 = typename TT<T>::v8;
     using v4 = typename TT<T>::v4;
     constexpr int TW = 16, PW = TW + 2, PH = TH + 2;
     constexpr int NPIECE = PH * PW * 8;                // 16-byte pieces per patch chunk
-    constexpr int NT = 512;
+    constexpr int NT = NW * 64;
+    constexpr int WAVES_M = NW / 2;
+    constexpr int NWP = 1024 / NT;                     // weight-tile pieces per thread
     constexpr int NROUND = (NPIECE + NT - 1) / NT;     // patch DMA rounds per chunk (the last one is partial)
     constexpr int NREMW = (NPIECE - (NROUND - 1) * NT + 63) / 64;    // waves with pieces in the last round
     constexpr int DUMP_OFF = (NROUND - 1) * NT * 16 + NREMW * 1024;  // dead slot for the other waves' last round
-    constexpr int PATCH_BYTES = DUMP_OFF + (NREMW < 8 ? 1024 : 0);
+    constexpr int PATCH_BYTES = DUMP_OFF + (NREMW < NW ? 1024 : 0);
     constexpr int BM = TH * TW;
-    constexpr int TM = BM / (4 * 32);                  // 32-pixel MFMA tiles per wave along M
+    constexpr int TM = BM / (WAVES_M * 32);            // 32-pixel MFMA tiles per wave along M
     constexpr int TN = 2;
-    static_assert(TM >= 1 && (TH / 4) % 2 == 0, "wave tiling");
+    static_assert(TM >= 1 && (TH / WAVES_M) % 2 == 0, "wave tiling");
     constexpr int WSTAGES = 4, W_BYTES = 128 * 128;
     constexpr int OFF_W = 2 * PATCH_BYTES;
     constexpr int OFF_SS = OFF_W + WSTAGES * W_BYTES;
@@ -198,7 +205,8 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
     // slot s of pixel (py, px) holds channel group s ^ ((px >> 1) & 7), which makes every ds_read_b128 lane
     // group of the fragment reads hit 16 distinct bank classes for all nine tap shifts.
     int p_full[NROUND];                                // source pixel index of the piece, -1: padding
-    int p_valid = 0, p_lcpack = 0;
+    int p_valid = 0;
+    uint64_t p_lcpack = 0;                             // 3 bits per round: source channel group of the piece
 #pragma unroll
     for (int r = 0; r < NROUND; ++r) {
         const int piece = r * NT + tid;
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
         const bool ok = piece < NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)Wd;
         p_full[r] = ok ? (b * H + iy) * Wd + ix : -1;                      // -1: out-of-range offset -> zeros
         p_valid |= ok ? (1 << r) : 0;
-        p_lcpack |= (pch ^ ((pxx >> 1) & 7)) << (3 * r);
+        p_lcpack |= (uint64_t)(pch ^ ((pxx >> 1) & 7)) << (3 * r);
     }
     auto patch_dma = [&](auto rc, const Chunk &c, int buf) {
         constexpr int r = decltype(rc)::value;
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
             const int ix = pix & (Wd - 1), iy = (pix >> lgW) & (H - 1), bb = pix >> (lgW + lgH);
             pix = pix < 0 ? -1 : ((((bb << (lgH - 1)) + (iy >> 1)) << (lgW - 1)) + (ix >> 1));
         }
-        const int lc16 = ((p_lcpack >> (3 * r)) & 7) << 4;
+        const int lc16 = (int)((p_lcpack >> (3 * r)) & 7) << 4;
         const unsigned voff = (unsigned)(pix * c.C2 + lc16);
         char *dst = smem + buf * PATCH_BYTES + ((r < NROUND - 1 || w < NREMW) ? r * (NT * 16) + w * 1024 : DUMP_OFF);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(uniform_rsrc(c.src, c.bytes), (lds_ptr_t)dst, 16, voff,
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
     };
     auto xf_slice = [&](auto rc, auto qc, const Chunk &c, u32x4 &x) {
         constexpr int r = decltype(rc)::value, q = decltype(qc)::value;
-        const int lc = (p_lcpack >> (3 * r)) & 7;
+        const int lc = (int)((p_lcpack >> (3 * r)) & 7);
         const bool valid = (p_valid >> r) & 1;
         const float *sc = ssL + c.ssbase + lc * 8 + 2 * q;
         const f32x2 s2 = *reinterpret_cast<const f32x2 *>(sc), h2 = *reinterpret_cast<const f32x2 *>(sc + a.ssC);
@@ -261,12 +269,13 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
     // ---- weight tiles: [128 rows][128 B] per tap, 1024 pieces, 2 per thread ----------------------------
     const __amdgpu_buffer_rsrc_t wrs = uniform_rsrc((const char *)a.Wgt + (size_t)n0 * a.Ktot * 2, 128 * a.Ktot * 2);
     const unsigned wvoff0 = (unsigned)(((tid >> 3) * a.Ktot + (((tid & 7) ^ ((tid >> 4) & 7)) << 3)) * 2);
-    const unsigned wvoff1 = wvoff0 + (unsigned)(64 * a.Ktot * 2);
+    const unsigned wvstep = (unsigned)((NT / 8) * a.Ktot * 2);          // NT/8 tile rows per block-wide instruction
     auto w_issue = [&](int slot, int kofs) {
         char *base = smem + OFF_W + slot * W_BYTES + w * 1024;
         const int so = __builtin_amdgcn_readfirstlane(kofs * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)base, 16, wvoff0, so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(base + 8192), 16, wvoff1, so, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NWP; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(base + i * (NT * 16)), 16, wvoff0 + i * wvstep, so, 0, 0);
     };
 
     f32x16 acc[TN][TM];
@@ -277,9 +286,9 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int wm = w & 3, wn = w >> 2;
+    const int wm = w % WAVES_M, wn = w / WAVES_M;
     const int q = l & 31, kh = l >> 5;
-    const int row_base = wm * (TH / 4);
+    const int row_base = wm * (TH / WAVES_M);
     const int lr = q >> 4, lcx = q & 15;
 
     // ---- fragment addresses ---------------------------------------------------------------------------
@@ -327,8 +336,10 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
     {
         const __amdgpu_buffer_rsrc_t srs =
             uniform_rsrc(a.ss ? a.ss + (size_t)b * 2 * a.ssC : (const float *)a.zeros, a.ss ? 2 * a.ssC * 4 : 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_ptr_t)(smem + OFF_SS + w * 1024), 16, (unsigned)(tid * 16), 0,
-                                                 0, 0);
+#pragma unroll
+        for (int i = 0; i < 512 / NT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_ptr_t)(smem + OFF_SS + i * (NT * 16) + w * 1024), 16,
+                                                     (unsigned)((i * NT + tid) * 16), 0, 0, 0);
     }
     if (nchunk9 > 0) {
         auto issue_all = [&](auto self, auto rc) {
@@ -343,7 +354,7 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
         w_issue(1, cur.kbase + cur.kstride);
         w_issue(2, cur.kbase + 2 * cur.kstride);
         w_issue(3, cur.kbase + 3 * cur.kstride);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // table + own patch pieces landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NWP) : "memory");      // table + own patch pieces landed
         __builtin_amdgcn_s_barrier();                         // ... in every wave (the table is shared)
         asm volatile("" ::: "memory");
         if (!(ABL & 8) && cur.ssbase >= 0) {
@@ -390,58 +401,73 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
         read_frags(IC<0>{}, IC<0>{}, IC<0>{});
         read_frags(IC<0>{}, IC<1>{}, IC<1>{});
     }
-    static_assert(NROUND - (NREMW < 8 ? 1 : 0) <= 5, "normalisation schedule: five full rounds + a partial one");
+    constexpr int NFULL = NROUND - (NREMW < NW ? 1 : 0);   // rounds in which every wave owns pieces
+    constexpr int RPW = (NFULL + 4) / 5;                   // full rounds normalised per window (windows of steps 3..7)
+    static_assert(RPW >= 1 && RPW <= 2, "normalisation schedule: five windows of one or two full rounds + a partial one");
     // The chunk body is instantiated with (DOX) and without the normalisation of the next chunk's patch, so that
     // the slices sit in the same basic block as the MFMAs and are interleaved with them.  A conv's 3x3 segments
     // are either all normalised or none (checked by the launcher): the loop over chunks 0..n-2 uses one variant,
     // the last chunk (no successor to prepare) always the plain one.
     auto chunk_body = [&](auto doxc, const int c) __attribute__((always_inline)) {
         constexpr bool DOX = decltype(doxc)::value != 0 && !(ABL & 8) && !(ABL & 16);
-        constexpr int NFULL = NROUND - (NREMW < 8 ? 1 : 0);    // rounds in which every wave owns pieces
-        u32x4 xa = {0u, 0u, 0u, 0u}, xb = {0u, 0u, 0u, 0u};    // round in flight (xb: the partial last round)
-        f32x2 sa = {0.f, 0.f}, ha = {0.f, 0.f};                // scale / shift of the slice in flight
-        // window of step s: positions 0..3 = phase 2, 3 of step s and phase 0, 1 of step s+1
+        u32x4 xa[RPW], xb = {0u, 0u, 0u, 0u};                  // rounds in flight (xb: the partial last round)
+        f32x2 sa[RPW], ha[RPW];                                // scale / shift of the slices in flight
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            xa[k] = u32x4{0u, 0u, 0u, 0u};
+            sa[k] = ha[k] = f32x2{0.f, 0.f};
+        }
+        // window of step s (3..7): positions 0..3 = phase 2, 3 of step s and phase 0, 1 of step s+1; it normalises
+        // the full rounds RPW*(s-3) .. RPW*(s-3)+RPW-1, two channels of each per position
         // xf_pre: LDS reads of the position, issued before the fragment reads of the phase
-        auto xf_pre = [&](auto sc, auto wc) {
-            constexpr int s = decltype(sc)::value, q = decltype(wc)::value;
-            constexpr int r = s >= 3 && s <= 7 && s - 3 < NFULL ? s - 3 : -1;
+        auto xf_pre1 = [&](auto sc, auto wc, auto kc) {
+            constexpr int s = decltype(sc)::value, q = decltype(wc)::value, k = decltype(kc)::value;
+            constexpr int r = s >= 3 && s <= 7 && RPW * (s - 3) + k < NFULL ? RPW * (s - 3) + k : -1;
             if constexpr (DOX && r >= 0) {
                 if constexpr (q == 0) {
                     // own piece landed?  (G_s is issued later in this phase: count up to G_(s-1))
                     if constexpr (!(ABL & 128))
-                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dmas_after_round(NROUND, r, s - 1)) : "memory");
-                    xf_begin(IC<r>{}, pbuf ^ 1, xa);
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dmas_after_round(NROUND, NWP, r, s - 1)) : "memory");
+                    xf_begin(IC<r>{}, pbuf ^ 1, xa[k]);
                 }
-                const int lc = (p_lcpack >> (3 * r)) & 7;
+                const int lc = (int)((p_lcpack >> (3 * r)) & 7);
                 const float *sc = ssL + nxt.ssbase + lc * 8 + 2 * q;
-                sa = *reinterpret_cast<const f32x2 *>(sc);
-                ha = *reinterpret_cast<const f32x2 *>(sc + a.ssC);
+                sa[k] = *reinterpret_cast<const f32x2 *>(sc);
+                ha[k] = *reinterpret_cast<const f32x2 *>(sc + a.ssC);
             }
         };
-        auto xf_math = [&](auto sc, auto wc) {
-            constexpr int s = decltype(sc)::value, q = decltype(wc)::value;
-            constexpr int r = s >= 3 && s <= 7 && s - 3 < NFULL ? s - 3 : -1;
+        auto xf_pre = [&](auto sc, auto wc) {
+            xf_pre1(sc, wc, IC<0>{});
+            if constexpr (RPW > 1) xf_pre1(sc, wc, IC<1>{});
+        };
+        auto xf_math1 = [&](auto sc, auto wc, auto kc) {
+            constexpr int s = decltype(sc)::value, q = decltype(wc)::value, k = decltype(kc)::value;
+            constexpr int r = s >= 3 && s <= 7 && RPW * (s - 3) + k < NFULL ? RPW * (s - 3) + k : -1;
             if constexpr (DOX && r >= 0) {
                 const bool valid = (p_valid >> r) & 1;
-                const unsigned xq = xa[q];
+                const unsigned xq = xa[k][q];
                 const v2 in = __builtin_bit_cast(v2, xq);
                 v2 o;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const float f = fmaf((float)in[e], sa[e], ha[e]);
+                    const float f = fmaf((float)in[e], sa[k][e], ha[k][e]);
                     o[e] = (T)(f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f)));
                 }
-                xa[q] = valid ? __builtin_bit_cast(unsigned, o) : xq;
-                if constexpr (q == 3) xf_end(IC<r>{}, pbuf ^ 1, xa);
+                xa[k][q] = valid ? __builtin_bit_cast(unsigned, o) : xq;
+                if constexpr (q == 3) xf_end(IC<r>{}, pbuf ^ 1, xa[k]);
             }
+        };
+        auto xf_math = [&](auto sc, auto wc) {
+            xf_math1(sc, wc, IC<0>{});
+            if constexpr (RPW > 1) xf_math1(sc, wc, IC<1>{});
         };
         // the partial last round (pieces of waves < NREMW only) slice by slice in the window of step 7
         auto xf_tail = [&](auto sc, auto wc) {
             constexpr int s = decltype(sc)::value, q = decltype(wc)::value;
-            if constexpr (DOX && NREMW < 8 && s == 7) {
+            if constexpr (DOX && NREMW < NW && s == 7) {
                 constexpr int r = NROUND - 1;
                 if constexpr (q == 0 && !(ABL & 128))
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dmas_after_round(NROUND, r, s)) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dmas_after_round(NROUND, NWP, r, s)) : "memory");
                 if (w < NREMW) {
                     if constexpr (q == 0) xf_begin(IC<r>{}, pbuf ^ 1, xb);
                     xf_slice(IC<r>{}, wc, nxt, xb);
@@ -452,14 +478,14 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
         // MFMAs of one phase with the slice of the window interleaved (1 MFMA : a few VALU)
         auto phase_math = [&](auto setc, auto sc, auto wc) {
             constexpr int s = decltype(sc)::value;
-            constexpr int r = s >= 3 && s <= 7 && s - 3 < NFULL ? s - 3 : -1;
+            constexpr int r = s >= 3 && s <= 7 && RPW * (s - 3) < NFULL ? RPW * (s - 3) : -1;
             multiply(setc);
             xf_math(sc, wc);
             if constexpr (DOX && r >= 0 && !(ABL & 1) && !(ABL & 256)) {
 #pragma unroll
                 for (int g = 0; g < TN * TM; ++g) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 20 / (TN * TM), 0);       // VALU in its shadow
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 20 * RPW / (TN * TM), 0);       // VALU in its shadow
                 }
             }
         };
@@ -502,7 +528,7 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
                 cur = nxt;
                 nxt = load_chunk(c + 2 < nchunk9 ? c + 2 : nchunk9 - 1);
             }
-            constexpr int N = rounds_at_tap(NROUND, t - 3) + 2 + rounds_at_tap(NROUND, t - 2) + 2 +
+            constexpr int N = rounds_at_tap(NROUND, t - 3) + NWP + rounds_at_tap(NROUND, t - 2) + NWP +
                               rounds_at_tap(NROUND, t - 1);
             mark(t, 1);
             if constexpr ((ABL & 128) != 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -523,9 +549,12 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
             }
             if constexpr (rounds_at_tap(NROUND, t) > 0) {
                 if (!(ABL & 8)) {
-                    patch_dma(IC<3 * t>{}, nxt, pbuf ^ 1);
-                    if constexpr (rounds_at_tap(NROUND, t) > 1) patch_dma(IC<(3 * t + 1 < NROUND ? 3 * t + 1 : 0)>{}, nxt, pbuf ^ 1);
-                    if constexpr (rounds_at_tap(NROUND, t) > 2) patch_dma(IC<(3 * t + 2 < NROUND ? 3 * t + 2 : 0)>{}, nxt, pbuf ^ 1);
+                    constexpr int R0 = rounds_per_tap(NROUND) * t, NR = rounds_at_tap(NROUND, t);
+                    static_assert(NR <= 4, "at most four patch rounds per tap");
+                    patch_dma(IC<R0>{}, nxt, pbuf ^ 1);
+                    if constexpr (NR > 1) patch_dma(IC<(NR > 1 ? R0 + 1 : 0)>{}, nxt, pbuf ^ 1);
+                    if constexpr (NR > 2) patch_dma(IC<(NR > 2 ? R0 + 2 : 0)>{}, nxt, pbuf ^ 1);
+                    if constexpr (NR > 3) patch_dma(IC<(NR > 3 ? R0 + 3 : 0)>{}, nxt, pbuf ^ 1);
                 }
             }
             phase_math(IC<(p0 + 2) % 3>{}, tc, IC<0>{});
@@ -696,19 +725,19 @@ __global__ __launch_bounds__(512) void conv_tap9(const FusedArgs a, const int ti
     }
 }
 
-template <typename T, int TH, int ABL>
+template <typename T, int TH, int ABL, int NW = 8>
 int launch_tap9_t(const FusedArgs &a, hipStream_t st) {
-    constexpr int NT = 512;
+    constexpr int NT = NW * 64;
     constexpr int NPIECE = (TH + 2) * 18 * 8, NROUND = (NPIECE + NT - 1) / NT;
     constexpr int NREMW = (NPIECE - (NROUND - 1) * NT + 63) / 64;
-    constexpr int PATCH_BYTES = (NROUND - 1) * NT * 16 + NREMW * 1024 + (NREMW < 8 ? 1024 : 0);
+    constexpr int PATCH_BYTES = (NROUND - 1) * NT * 16 + NREMW * 1024 + (NREMW < NW ? 1024 : 0);
     constexpr int main_bytes = 2 * PATCH_BYTES + 4 * 16384 + 8192 + TAP9_MAX_CHUNKS * 32;
     constexpr int epi_bytes = TH * 16 * 256 + (NT / 16) * 128 * 2 * 4;
     constexpr int smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr = false;
     if (!attr) {
-        BNDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_tap9<T, TH, ABL>),
+        BNDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_tap9<T, TH, ABL, NW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr = true;
     }
@@ -720,7 +749,7 @@ int launch_tap9_t(const FusedArgs &a, hipStream_t st) {
         if (!buf) BNDM_CHECK_HIP(hipMalloc(&buf, 8 * 9 * 6 * sizeof(unsigned)));
         dbg = buf;
     }
-    hipLaunchKernelGGL((conv_tap9<T, TH, ABL>), grid, dim3(NT), smem, st, a, tiles_x, tps, ntn, dbg);
+    hipLaunchKernelGGL((conv_tap9<T, TH, ABL, NW>), grid, dim3(NT), smem, st, a, tiles_x, tps, ntn, dbg);
     if constexpr ((ABL & 64) != 0) {
         // profiling aid: dump the marks of 4-chunk launches (the K = 2304 layers) as text
         int n9 = 0;
@@ -731,7 +760,7 @@ int launch_tap9_t(const FusedArgs &a, hipStream_t st) {
             BNDM_CHECK_HIP(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
             FILE *f = fopen(getenv("BNDM_TAP9_TRACE"), "w");
             if (f) {
-                for (int w = 0; w < 8; ++w)
+                for (int w = 0; w < NW; ++w)
                     for (int t = 0; t < 9; ++t) {
                         fprintf(f, "w%d t%d", w, t);
                         for (int k = 0; k < 6; ++k) fprintf(f, " %u", h[(w * 9 + t) * 6 + k] - h[0]);
@@ -767,8 +796,9 @@ bool conv_tap9_supports(const FusedArgs &a) {
 
 int launch_conv_tap9(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
     static const int abl = getenv("BNDM_ABLATE") ? atoi(getenv("BNDM_ABLATE")) : 0;
+    static const int nw = getenv("BNDM_TAP9_NW") ? atoi(getenv("BNDM_TAP9_NW")) : 8;      // waves per block: 8 or 4
     if (dtype == BNDM_DTYPE_F16) {
-        if (abl && TH == 16) {
+        if (abl && TH == 16 && !(abl == 64 && nw == 4)) {
             switch (abl) {
                 case 1: return launch_tap9_t<_Float16, 16, 1>(a, st);
                 case 2: return launch_tap9_t<_Float16, 16, 2>(a, st);
@@ -792,8 +822,11 @@ int launch_conv_tap9(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
             }
         }
         if (abl == 128 && TH == 8) return launch_tap9_t<_Float16, 8, 128>(a, st);
+        if (abl == 64 && nw == 4 && TH == 16) return launch_tap9_t<_Float16, 16, 64, 4>(a, st);
+        if (nw == 4) return TH == 16 ? launch_tap9_t<_Float16, 16, 0, 4>(a, st) : launch_tap9_t<_Float16, 8, 0, 4>(a, st);
         return TH == 16 ? launch_tap9_t<_Float16, 16, 0>(a, st) : launch_tap9_t<_Float16, 8, 0>(a, st);
     }
+    if (nw == 4) return TH == 16 ? launch_tap9_t<__bf16, 16, 0, 4>(a, st) : launch_tap9_t<__bf16, 8, 0, 4>(a, st);
     return TH == 16 ? launch_tap9_t<__bf16, 16, 0>(a, st) : launch_tap9_t<__bf16, 8, 0>(a, st);
 }
 
