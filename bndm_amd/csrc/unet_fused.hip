@@ -802,7 +802,10 @@ int launch_conv_fused(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
         return BNDM_E_ARG;
     }
     static const int ver = getenv("BNDM_FUSED_V") ? atoi(getenv("BNDM_FUSED_V")) : 9;
-    if (ver == 9 && conv_tap9_supports(a) && conv_fused_threads(TH) == 512) return launch_conv_tap9(dtype, TH, a, st);
+    if (ver == 9 && conv_tap9_supports(a) && conv_fused_threads(TH) == 512) {
+        static const int spec = getenv("BNDM_TAP9_SPEC") ? atoi(getenv("BNDM_TAP9_SPEC")) : 0;
+        return spec ? launch_conv_tap9s(dtype, TH, a, st) : launch_conv_tap9(dtype, TH, a, st);
+    }
     static const int abl = getenv("BNDM_ABLATE") ? atoi(getenv("BNDM_ABLATE")) : 0;
     if (dtype == BNDM_DTYPE_F16) {
         if (abl && TH == 16) {       // profiling-only variants (f16, 256-pixel tiles)

@@ -129,6 +129,8 @@ int conv_fused_threads(int TH);
 // tap-unrolled variant of the same kernel (unet_tap9.hip); used whenever it supports the segment list
 bool conv_tap9_supports(const FusedArgs &a);
 int launch_conv_tap9(int dtype, int TH, const FusedArgs &a, hipStream_t st);
+// the same kernel with specialised waves (8 MFMA waves + 4 patch-DMA / normalisation waves; unet_tap9s.hip)
+int launch_conv_tap9s(int dtype, int TH, const FusedArgs &a, hipStream_t st);
 
 // one-launch GroupNorm(+SiLU) for small per-sample tensors (statistics + apply, one block per sample)
 // x1 given as split-K partial sums: element = round16(sum_z part[z] + bias + temb + resid); the rounded value is also
