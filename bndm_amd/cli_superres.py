@@ -2,8 +2,8 @@
 
 x_c = bilinear 4x down + 4x up of the target (align_corners=True, :624-626), x0 = white noise through
 ``get_noise_v2(..., inplace=True)`` (:630-633), ``sample_iadb_conditional`` with a 6-channel-input UNet
-(:635), PSNR / L1 / L2 against the target (the reference's ``piq`` SSIM is not available offline and is
-skipped).  Test images are read from ``./data/<dataset>_test/*/*.png|jpg`` with PIL; without that folder a
+(:635), SSIM / PSNR / L1 / L2 against the target (``piq`` is not available offline; bndm_amd/metrics.py restates
+its defaults).  Test images are read from ``./data/<dataset>_test/*/*.png|jpg`` with PIL; without that folder a
 seeded synthetic target is used so that the path can be exercised.
 """
 from __future__ import annotations
@@ -78,7 +78,8 @@ def run_conditional(opt, device, rank, world):
     if not real:
         say(f"[bndm] ./data/{opt.dataset}_test not found: using seeded synthetic targets")
         picks = range(1, min(len(targets), 4) + 1)
-    psnr_sum, l1_sum, l2_sum, cnt = 0.0, 0.0, 0.0, 0
+    psnr_sum, ssim_sum, l1_sum, l2_sum, cnt = 0.0, 0.0, 0.0, 0.0, 0
+    from .metrics import ssim
     from PIL import Image
     for idx in picks:
         if idx > len(targets) or (idx - 1) % world != rank:
@@ -99,6 +100,7 @@ def run_conditional(opt, device, rank, world):
         ref = (x1 + 1) / 2
         mse = torch.mean((rec - ref) ** 2).item()
         psnr_sum += 10 * np.log10(1.0 / max(mse, 1e-12))
+        ssim_sum += float(ssim(rec, ref, data_range=1.0)[0])                      # iadb_bn.py:639
         l2_sum += torch.sum((sample - x1) ** 2).item()
         l1_sum += torch.sum(torch.abs(sample - x1)).item()
         cnt += 1
@@ -110,6 +112,6 @@ def run_conditional(opt, device, rank, world):
             Image.fromarray(export_u8(x_c, "trunc")[0].cpu().numpy()).save(
                 os.path.join(out_dir, folder, "lowres", f"lowres_{tag}_{idx:05d}.png"))
     if cnt:
-        print(f"[rank {rank}] conditional metrics over {cnt} images: psnr {psnr_sum / cnt:.4f}, "
+        print(f"[rank {rank}] conditional metrics over {cnt} images: ssim {ssim_sum / cnt:.4f}, psnr {psnr_sum / cnt:.4f}, "
               f"l1 {l1_sum / cnt:.2f}, l2 {l2_sum / cnt:.2f}")
     return 0

@@ -86,3 +86,21 @@ def test_host_schedules_match_goldens(golden_dir):
         else:
             got = get_scheduler_gamma(t, parts[1], torch.tensor(eval(parts[3])), N)
         assert np.array_equal(got.numpy(), g[key]), key
+
+
+def test_metrics_ssim_psnr_properties():
+    """bndm_amd/metrics.py (restatement of the piq calls at iadb_bn.py:636-644): identities and monotonicity."""
+    import torch
+    from bndm_amd.metrics import psnr, ssim
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(2, 3, 64, 64, generator=g)
+    assert torch.allclose(ssim(x, x), torch.ones(2, dtype=torch.float64))
+    n1 = (x + 0.05 * torch.randn(x.shape, generator=g)).clamp(0, 1)
+    n2 = (x + 0.20 * torch.randn(x.shape, generator=g)).clamp(0, 1)
+    s1, s2 = ssim(x, n1), ssim(x, n2)
+    assert (s1 > s2).all() and (s2 > 0).all() and (s1 < 1).all()
+    assert torch.allclose(ssim(x, n1), ssim(n1, x))
+    assert (psnr(x, n1) > psnr(x, n2)).all()
+    flat = torch.full((1, 1, 32, 32), 0.5)
+    assert abs(float(psnr(flat, flat + 0.1)) - 20.0) < 1e-4           # mse = 0.01 -> 20 dB
+    assert ssim(torch.rand(1, 3, 512, 512, generator=g), torch.rand(1, 3, 512, 512, generator=g)).shape == (1,)
