@@ -487,7 +487,9 @@ struct Builder {
         a.W = out.W;
         a.Cout = out.C;
         a.zeros = h->zeros;
-        const int TH = out.H >= 32 ? 16 : 8;
+        // 256-pixel tiles unless that leaves CUs idle at this handle's batch size (small per-GPU batches)
+        int TH = out.H >= 32 ? 16 : 8;
+        if (TH == 16 && (long long)h->cfg.max_batch * (out.H / 16) * (out.W / 16) * (out.C / 128) < 192) TH = 8;
         {
             const std::vector<int> tab = build_fused_steps(a.seg, a.nseg, TH, conv_fused_threads(TH));
             void *dtab;

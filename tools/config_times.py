@@ -73,5 +73,5 @@ def c5():
 
 
 if __name__ == "__main__":
-    for f in (c3, c4, c5):
+    for f in ((c3, c4, c5) if len(sys.argv) < 2 else [globals()[a] for a in sys.argv[1:]]):
         f()
