@@ -221,7 +221,8 @@ def main():
                        "global_batch": B * args.gpus, "nb_steps": N, "parallelism": f"batch-shard x{args.gpus}"},
             "roofline": roof,
             "stages": stages,
-            "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(N),
+            # timed on rank 0 of the single-GPU run only (the host cores are shared by the ranks otherwise)
+            "cpu_baseline": None if (args.no_cpu_baseline or args.gpus > 1) else cpu_baseline(N),
         }
         print(json.dumps(line), flush=True)
     barrier()
