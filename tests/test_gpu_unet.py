@@ -183,3 +183,36 @@ def test_conditional_superres_loop_matches_oracle():
     got, snaps = sample_iadb_conditional(m, x0.cuda(), x_c.cuda(), 4, "sigmoid", params.cuda(), 6, "gaussianBN", "test")
     assert len(snaps) == len(ref_snaps)
     assert _rel(got.cpu(), ref) <= 2e-3
+
+
+@pytest.mark.parametrize("env", [{"BNDM_TAP9_SPEC": "1"}, {"BNDM_TAP9_NW": "4"}, {"BNDM_FUSED_V": "6"},
+                                 {"BNDM_NO_DEFER": "1", "BNDM_NO_GN_SMALL": "1"}])
+def test_alternative_kernel_paths_match_oracle(env):
+    """The opt-in variants of the fused conv (wave-specialised conv_tap9s, 4-wave conv_tap9, the previous
+    conv_fused) and the un-fused GroupNorm / split-K reduce path are selected by process-wide environment
+    switches: run one forward of a 3-level network in a child process per setting, same bar as the default."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import sys, torch
+        sys.path.insert(0, %r)
+        from oracle import unet_oracle as U
+        from bndm_amd.unet import UNet2DModel
+        cfg = dict(in_channels=3, out_channels=6, block_out_channels=(128, 128, 256), down_attn=(False, False, False),
+                   up_attn=(False, False, False), layers_per_block=2)
+        sd = U.init_params(cfg, seed=5, perturb_norm=0.1)
+        x = torch.randn(3, 3, 64, 64, generator=torch.Generator().manual_seed(0))
+        t = torch.tensor([0.9, 0.5, 0.1])
+        ref = U.forward(sd, cfg, x, t)
+        m = UNet2DModel(in_channels=3, out_channels=6, block_out_channels=(128, 128, 256),
+                        down_block_types=("DownBlock2D",) * 3, up_block_types=("UpBlock2D",) * 3)
+        m.load_state_dict(sd)
+        got = m.cuda()(x.cuda(), t.cuda(), return_dict=False)[0].cpu()
+        print("REL", float((got - ref).double().norm() / ref.double().norm()))
+    ''' % root)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rel = float([ln for ln in out.stdout.splitlines() if ln.startswith("REL")][-1].split()[1])
+    print(env, rel)
+    assert rel <= 2e-3
