@@ -201,8 +201,8 @@ def test_alternative_kernel_paths_match_oracle(env):
         cfg = dict(in_channels=3, out_channels=6, block_out_channels=(128, 128, 256), down_attn=(False, False, False),
                    up_attn=(False, False, False), layers_per_block=2)
         sd = U.init_params(cfg, seed=5, perturb_norm=0.1)
-        x = torch.randn(3, 3, 64, 64, generator=torch.Generator().manual_seed(0))
-        t = torch.tensor([0.9, 0.5, 0.1])
+        x = torch.randn(12, 3, 64, 64, generator=torch.Generator().manual_seed(0))    # 12: 256-pixel tiles at 64x64
+        t = torch.linspace(0.05, 1.0, 12)
         ref = U.forward(sd, cfg, x, t)
         m = UNet2DModel(in_channels=3, out_channels=6, block_out_channels=(128, 128, 256),
                         down_block_types=("DownBlock2D",) * 3, up_block_types=("UpBlock2D",) * 3)
