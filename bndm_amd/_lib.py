@@ -59,6 +59,8 @@ SIGNATURES = {
     "bndm_unet_param_info": (_i, [_vp, _i, C.c_char_p, _sz, C.POINTER(C.c_int64)]),
     "bndm_unet_load_param": (_i, [_vp, C.c_char_p, _vp, C.c_int64]),
     "bndm_unet_finalize": (_i, [_vp]),
+    "bndm_unet_num_ops": (_i, [_vp]),
+    "bndm_unet_op_info": (_i, [_vp, _i, C.c_char_p, _sz, C.c_char_p, _sz, C.POINTER(C.c_double)]),
     "bndm_unet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "bndm_unet_sample_iadb": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bndm_unet_sample_ddim": (_i, [_vp, _vp, _i, _i, _vp, _f, _vp]),

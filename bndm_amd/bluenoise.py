@@ -18,28 +18,26 @@ Z_COLUMNS, Z_IMAGE32, Z_IMAGE128 = 0, 1, 2
 MODE_BLEND, MODE_PURE_BN, MODE_SCRAMBLE = 0, 1, 2
 
 _BN_TYPES = ("gaussianBN", "gaussianRN", "GBN")
-_tri_cache: dict = {}
 
 
 def _is_lower_triangular(L: torch.Tensor) -> bool:
-    """True when L is exactly zero above the diagonal (then only j<=i is read).  Checked once per
-    tensor version; a factor with anything above the diagonal takes the dense path, which is the
-    reference's semantics for arbitrary matrices."""
-    key = (L.data_ptr(), L._version, tuple(L.shape))
-    hit = _tri_cache.get(key)
-    if hit is None:
-        hit = bool((torch.triu(L, diagonal=1) == 0).all().item())
-        if len(_tri_cache) > 16:
-            _tri_cache.clear()
-        _tri_cache[key] = hit
-    return hit
+    """True when L is exactly zero above the diagonal (then only j<=i is read).  Probed once per tensor object
+    and version -- the result rides on the tensor itself, so a new factor allocated at a recycled address is
+    probed again; a factor with anything above the diagonal takes the dense path, which is the reference's
+    semantics for arbitrary matrices.  The probe reads the 64 MiB matrix and synchronises (one ``.item()``):
+    pass ``l_is_triangular=`` to ``get_noise_v2`` to skip it."""
+    hit = getattr(L, "_bndm_tri", None)
+    if hit is None or hit[0] != L._version:
+        hit = (L._version, bool((torch.triu(L, diagonal=1) == 0).all().item()))
+        L._bndm_tri = hit
+    return hit[1]
 
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def _run(L, z, z_layout, alpha, B_global, b_begin, b_count, Cch, res, mode, want_parts=True):
+def _run(L, z, z_layout, alpha, B_global, b_begin, b_count, Cch, res, mode, want_parts=True, tri=None):
     lib = _lib.load()
     dev = z.device
     shape = (b_count, Cch, res, res)
@@ -52,7 +50,7 @@ def _run(L, z, z_layout, alpha, B_global, b_begin, b_count, Cch, res, mode, want
         noise_wn = torch.empty(shape, dtype=torch.float32, device=dev) if want_parts else None
         ws_bytes = lib.bndm_bluenoise_workspace_bytes(b_count, Cch, res)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        dense = 0 if _is_lower_triangular(L) else 1
+        dense = 0 if (_is_lower_triangular(L) if tri is None else tri) else 1
     rc = lib.bndm_bluenoise(_ptr(L), dense, _ptr(z), z_layout, _ptr(alpha), _ptr(noise), _ptr(noise_bn),
                             _ptr(noise_wn), B_global, b_begin, b_count, Cch, res, mode, _ptr(ws), ws_bytes,
                             _lib.current_stream_ptr())
@@ -86,13 +84,15 @@ def noise_padding(noise_small, res=128):
 
 
 def get_noise_v2(device, x, cov_mat_L, alpha_t, time_step, noise_type='gaussian', train_or_test='train',
-                 inplace=False, *, batch_range=None, global_z=None):
+                 inplace=False, *, batch_range=None, global_z=None, l_is_triangular=None):
     """Drop-in for bluenoise.get_noise_recent.get_noise_v2 (get_noise_recent.py:23).
 
     Extra keyword-only arguments (not in the reference) serve batch sharding across GPUs
     (SURVEY.md 8e): ``batch_range=(b_begin, b_count)`` computes only those samples of the global
     batch ``x`` -- the 128-px branch mixes tiles across the batch, so every rank passes the global
-    ``x`` (or ``global_z``) and its own range.
+    ``x`` (or ``global_z``) and its own range.  ``l_is_triangular`` (True / False) states whether ``cov_mat_L`` is
+    exactly zero above its diagonal (a Cholesky factor is); ``None`` probes the matrix once per tensor, which
+    reads 64 MiB and synchronises on first use.
     """
     res = x.shape[-1]
     Cch = x.shape[1]
@@ -153,7 +153,7 @@ def get_noise_v2(device, x, cov_mat_L, alpha_t, time_step, noise_type='gaussian'
             # same here so a seeded run consumes the same stream
             z = global_z if global_z is not None else torch.randn(B * 4, Cch, 64, 64).float().to(device)
             z, layout = z.contiguous(), Z_COLUMNS
-    return _run(cov_mat_L, z, layout, alpha, B, b_begin, b_count, Cch, res, mode)
+    return _run(cov_mat_L, z, layout, alpha, B, b_begin, b_count, Cch, res, mode, tri=l_is_triangular)
 
 
 # README.md:33 calls it ``get_noise``; the code never defined that name.  Provide the alias.

@@ -155,6 +155,7 @@ def main(argv=None):
         if picks is not None and i not in picks:
             continue
         B = last_bs if i == num_batch - 1 else opt.batch_size
+        cur_bs = B                                                       # cur_batch_size of iadb_bn.py:757-759
         # the global numpy stream is consumed exactly as at iadb_bn.py:761 (rank-independent)
         x0 = torch.from_numpy(np.random.randn(B, 3, opt.res, opt.res)).float()
         if not opt.full_batches:
@@ -187,7 +188,8 @@ def main(argv=None):
         if bc > 0:
             sample, sample_all, ft = sample_iadb(model, x0, opt.nb_steps, opt.scheduler_gamma, scheduler_params,
                                                  opt.out_channel, opt.noise_type, "test",
-                                                 scheduler_alpha=opt.scheduler_alpha, log_freq=25)
+                                                 scheduler_alpha=opt.scheduler_alpha, log_freq=25,
+                                                 alpha_param=opt.scheduler_param)      # iadb_bn.py:115,131
             fwd_times.append(ft)
             u8 = export_u8(sample, "trunc")
         else:
@@ -204,9 +206,12 @@ def main(argv=None):
                 _save_png(arr, os.path.join(out_dir, folder, "seqs",
                                             f"{tag}_img{cnt:05d}_step{int((j * 100) / 1000 * opt.nb_steps)}.png"))
             imgs = imgs.cpu().numpy()
-            for j in range(B):
+            # iadb_bn.py:808-816: cnt advances once per sample of the batch (batch_size of them), also in
+            # replicability mode, where only sample 0 is kept -- 00001.png, 00501.png, ... at batch_size 500
+            for j in range(cur_bs):
                 cnt += 1
-                _save_png(imgs[j], os.path.join(out_dir, folder, "images", f"{cnt:05d}.png"))
+                if j < B:
+                    _save_png(imgs[j], os.path.join(out_dir, folder, "images", f"{cnt:05d}.png"))
     say("np.mean(inference_times) per UNet forward", float(np.mean(fwd_times)) if fwd_times else float("nan"))
     say("np.mean(noise_gen_times)", float(np.mean(noise_times[1:])) if len(noise_times) > 1 else float("nan"))
     return 0

@@ -81,21 +81,28 @@ def run_conditional(opt, device, rank, world):
     psnr_sum, ssim_sum, l1_sum, l2_sum, cnt = 0.0, 0.0, 0.0, 0.0, 0
     from .metrics import ssim
     from PIL import Image
-    for idx in picks:
-        if idx > len(targets) or (idx - 1) % world != rank:
+    for order, idx in enumerate(picks):
+        if idx > len(targets):
+            continue
+        # every rank consumes the draw of every pick (the reference's single numpy stream, iadb_bn.py:631), so the
+        # images do not depend on the number of ranks; a rank keeps the picks it owns
+        x0_np = np.random.randn(1, 3, opt.res, opt.res)
+        cnt_name = order + 1                                              # running cnt of iadb_bn.py:662
+        if order % world != rank:
             continue
         x1 = torch.from_numpy(targets[idx - 1])[None].to(device) * 2 - 1
         lo = opt.res // 4
         x_c = torch.nn.functional.interpolate(x1, size=(lo, lo), mode="bilinear", align_corners=True)
         x_c = torch.nn.functional.interpolate(x_c, size=(opt.res, opt.res), mode="bilinear", align_corners=True)
-        x0 = torch.from_numpy(np.random.randn(1, 3, opt.res, opt.res)).float().to(device)
+        x0 = torch.from_numpy(x0_np).float().to(device)
         t = torch.full((1,), opt.nb_steps, device=device)
         gamma_t = get_scheduler_gamma(t.float(), opt.scheduler_gamma, scheduler_params, opt.nb_steps)
         x0, _, _ = get_noise_v2(device, x0, cov_mat_L, gamma_t, t, noise_type=opt.noise_type, train_or_test="test",
                                 inplace=True)
         sample, sample_all = sample_iadb_conditional(model, x0, x_c, opt.nb_steps, opt.scheduler_gamma,
                                                      scheduler_params, opt.out_channel, opt.noise_type, "test",
-                                                     scheduler_alpha=opt.scheduler_alpha)
+                                                     scheduler_alpha=opt.scheduler_alpha,
+                                                     alpha_param=opt.scheduler_param)
         rec = torch.clamp((sample + 1) / 2, 0, 1)
         ref = (x1 + 1) / 2
         mse = torch.mean((rec - ref) ** 2).item()
@@ -105,12 +112,12 @@ def run_conditional(opt, device, rank, world):
         l1_sum += torch.sum(torch.abs(sample - x1)).item()
         cnt += 1
         u8 = export_u8(sample, "trunc")[0].cpu().numpy()
-        Image.fromarray(u8).save(os.path.join(out_dir, folder, "images", f"image_{tag}_{idx:05d}.png"))
+        Image.fromarray(u8).save(os.path.join(out_dir, folder, "images", f"image_{tag}_{cnt_name:05d}.png"))
         if opt.noise_type == "gaussian":
             Image.fromarray(export_u8(x1, "trunc")[0].cpu().numpy()).save(
-                os.path.join(out_dir, folder, "highres", f"highres_{tag}_{idx:05d}.png"))
+                os.path.join(out_dir, folder, "highres", f"highres_{tag}_{cnt_name:05d}.png"))
             Image.fromarray(export_u8(x_c, "trunc")[0].cpu().numpy()).save(
-                os.path.join(out_dir, folder, "lowres", f"lowres_{tag}_{idx:05d}.png"))
+                os.path.join(out_dir, folder, "lowres", f"lowres_{tag}_{cnt_name:05d}.png"))
     if cnt:
         print(f"[rank {rank}] conditional metrics over {cnt} images: ssim {ssim_sum / cnt:.4f}, psnr {psnr_sum / cnt:.4f}, "
               f"l1 {l1_sum / cnt:.2f}, l2 {l2_sum / cnt:.2f}")

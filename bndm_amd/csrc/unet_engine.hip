@@ -107,6 +107,7 @@ struct Op {
     bool dominant = false;          // conv_fused, 256-pixel tiles
     double bytes_per_sample = 0;    // algorithmic HBM bytes per batch element (activations)
     double bytes_fixed = 0;         // weights
+    std::string kernel;             // kernel family (and tile variant) this op launches, e.g. "conv_tap9<TH=16>"
 };
 
 }  // namespace
@@ -131,6 +132,9 @@ struct bndm_unet {
     float *tp_table = nullptr, *t_steps = nullptr;
     void *act_steps = nullptr;
     int tp_cap = 0;
+    float *t_pinned = nullptr;           // host staging of the step times (pinned: the upload is truly asynchronous)
+    hipEvent_t t_uploaded = nullptr;     // recorded after that upload; the next call waits for it before rewriting
+    std::vector<void *> retired;         // outgrown tables, released with the handle (earlier launches may still read them)
     std::function<int(int, const float *, void *, float *, hipStream_t)> temb_table_fn;
 
     // fixed scratch slots
@@ -359,6 +363,16 @@ struct Builder {
     std::string cur_name;
     void push(int cls, double flops, std::function<int(RunCtx &)> fn) {
         h->ops.push_back(Op{cls, flops, std::move(fn), cur_name});
+        // kernel family from the op label's four-letter tag; conv_fused() overwrites it with the tile variant
+        static const std::pair<const char *, const char *> fam[] = {
+            {"cnvF", "conv_tap9"}, {"conv", "conv_igemm"}, {"gnst", "gn_stats"}, {"gnfn", "gn_finalize2"},
+            {"gnsm", "gn_small"}, {"gnap", "gn_apply"}, {"rdce", "splitk_reduce"}, {"attn", "attention"},
+            {"temb", "temb_mlp"}, {"post", "pointwise_f32"}, {"deco", "conv_in"}};
+        Op &op = h->ops.back();
+        op.kernel = cur_name.substr(0, cur_name.find(' '));
+        for (const auto &f : fam)
+            if (cur_name.compare(0, 4, f.first) == 0) op.kernel = f.second;
+        if (cur_name.compare(0, 7, "conv_in") == 0 || cur_name == "decoder.conv_in") op.kernel = "conv_in";
     }
 
     // per-(sample, channel) partial sums of x: produced by the fused conv epilogue when possible,
@@ -518,6 +532,7 @@ struct Builder {
             return launch_conv_fused(hh->dtype(), TH, c, r.st);
         });
         h->ops[op_index].dominant = TH == 16;
+        h->ops[op_index].kernel = S("conv_tap9<TH=%d>", TH);
         h->ops[op_index].bytes_per_sample = abytes;
         h->ops[op_index].bytes_fixed = wbytes;
     }
@@ -1213,18 +1228,24 @@ int run_forward(bndm_unet *h, RunCtx &r) {
 
 // time-embedding projections of every step of a schedule, computed once per sampling call (K10)
 int prepare_temb_table(bndm_unet *h, int n, const float *t_host, hipStream_t st) {
+    if (!h->t_uploaded) BNDM_CHECK_HIP(hipEventCreateWithFlags(&h->t_uploaded, hipEventDisableTiming));
+    else BNDM_CHECK_HIP(hipEventSynchronize(h->t_uploaded));      // the previous call's upload has left t_pinned
     if (n > h->tp_cap) {
-        BNDM_CHECK_HIP(hipStreamSynchronize(st));
-        if (h->tp_table) (void)hipFree(h->tp_table);
-        if (h->t_steps) (void)hipFree(h->t_steps);
-        if (h->act_steps) (void)hipFree(h->act_steps);
-        h->tp_table = nullptr; h->t_steps = nullptr; h->act_steps = nullptr; h->tp_cap = 0;
+        // no stream synchronisation: launches already queued may still read the old tables, so they are kept until
+        // the handle is destroyed (a schedule table is n * ntemb floats, ~10 MB for 250 steps)
+        for (void *p : {(void *)h->tp_table, (void *)h->t_steps, h->act_steps})
+            if (p) h->retired.push_back(p);
+        if (h->t_pinned) (void)hipHostFree(h->t_pinned);
+        h->tp_table = nullptr; h->t_steps = nullptr; h->act_steps = nullptr; h->t_pinned = nullptr; h->tp_cap = 0;
         BNDM_CHECK_HIP(hipMalloc((void **)&h->tp_table, (size_t)n * h->ntemb * 4));
         BNDM_CHECK_HIP(hipMalloc((void **)&h->t_steps, (size_t)n * 4));
         BNDM_CHECK_HIP(hipMalloc(&h->act_steps, (size_t)n * h->temb_dim * 2));
+        BNDM_CHECK_HIP(hipHostMalloc((void **)&h->t_pinned, (size_t)n * 4, hipHostMallocDefault));
         h->tp_cap = n;
     }
-    BNDM_CHECK_HIP(hipMemcpyAsync(h->t_steps, t_host, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    memcpy(h->t_pinned, t_host, (size_t)n * 4);
+    BNDM_CHECK_HIP(hipMemcpyAsync(h->t_steps, h->t_pinned, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    BNDM_CHECK_HIP(hipEventRecord(h->t_uploaded, st));
     return h->temb_table_fn(n, h->t_steps, h->act_steps, h->tp_table, st);
 }
 
@@ -1271,6 +1292,10 @@ extern "C" int bndm_unet_create(bndm_unet **out, const bndm_unet_config *cfg) {
         BNDM_REQUIRE(cfg->block_out_channels[i] % 64 == 0 && cfg->block_out_channels[i] <= 512,
                      "bndm_unet_create: block_out_channels[%d]=%d must be a multiple of 64 and <= 512", i,
                      cfg->block_out_channels[i]);
+    // conv_in_kernel / temb_mlp_kernel layouts: 256 threads cover C0/8 16-byte chunks per pixel row, D = 4*C0 <= 1024
+    BNDM_REQUIRE(cfg->block_out_channels[0] == 64 || cfg->block_out_channels[0] == 128 ||
+                     cfg->block_out_channels[0] == 256,
+                 "bndm_unet_create: block_out_channels[0]=%d must be 64, 128 or 256", cfg->block_out_channels[0]);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
         (void)hipGetLastError();
@@ -1346,6 +1371,9 @@ extern "C" void bndm_unet_destroy(bndm_unet *h) {
     if (h->tp_table) (void)hipFree(h->tp_table);
     if (h->t_steps) (void)hipFree(h->t_steps);
     if (h->act_steps) (void)hipFree(h->act_steps);
+    if (h->t_pinned) (void)hipHostFree(h->t_pinned);
+    if (h->t_uploaded) (void)hipEventDestroy(h->t_uploaded);
+    for (void *p : h->retired) (void)hipFree(p);
     for (Buf &b : h->bufs)
         if (b.ptr) (void)hipFree(b.ptr);
     delete h;
@@ -1373,6 +1401,18 @@ extern "C" int bndm_unet_load_param(bndm_unet *h, const char *name, const float 
                  (long long)ps.numel, (long long)numel);
     h->host[it->second].assign(host_data, host_data + numel);
     h->loaded[it->second] = 1;
+    return 0;
+}
+
+extern "C" int bndm_unet_num_ops(const bndm_unet *h) { return h && h->finalized ? (int)h->ops.size() : 0; }
+
+extern "C" int bndm_unet_op_info(const bndm_unet *h, int index, char *kernel, size_t kernel_len, char *label,
+                                 size_t label_len, double *flops_per_sample) {
+    BNDM_REQUIRE(h && h->finalized && index >= 0 && index < (int)h->ops.size(), "bndm_unet_op_info: bad index %d", index);
+    const Op &op = h->ops[index];
+    if (kernel && kernel_len) snprintf(kernel, kernel_len, "%s", op.kernel.c_str());
+    if (label && label_len) snprintf(label, label_len, "%s", op.name.c_str());
+    if (flops_per_sample) *flops_per_sample = op.flops_per_sample;
     return 0;
 }
 
@@ -1453,8 +1493,7 @@ extern "C" int bndm_unet_sample_ddim(bndm_unet *h, float *x, int B, int nb_step,
     if (nb_step > 0) {
         std::vector<float> ts(nb_step);
         for (int s = 0; s < nb_step; ++s) ts[s] = coef[5 * s];
-        if ((rc = prepare_temb_table(h, nb_step, ts.data(), st))) return rc;
-        BNDM_CHECK_HIP(hipStreamSynchronize(st));      // ts is a stack-lifetime host buffer
+        if ((rc = prepare_temb_table(h, nb_step, ts.data(), st))) return rc;     // copied to pinned staging there
     }
     for (int s = 0; s < nb_step; ++s) {
         const float *c = coef + 5 * s;

@@ -525,6 +525,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float *__restrict__ 
     }
     if (stats) {
         float *red = reinterpret_cast<float *>(smem + 128 * rowB);     // [RP][C0][2]
+        if (prw < RP)                                                  // (256 % CH != 0 would leave spare threads)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             red[((prw * C0) + c16 * 8 + e) * 2 + 0] = s1[e];

@@ -55,7 +55,7 @@ def _snap_mask(nb_step, train_or_test, log_freq):
 
 
 def _iadb_loop(model, x0, x_c, nb_step, scheduler_alpha, scheduler_gamma, scheduler_params, out_channel,
-               noise_type, train_or_test, log_freq, alpha_param=0.02):
+               noise_type, train_or_test, log_freq, alpha_param=0.02, tables=None):
     _lib.require_gpu(x0, "sample_iadb(x0)")
     if noise_type not in ("gaussianBN", "gaussianRN", "gaussian", "GBN"):
         raise NotImplementedError
@@ -67,7 +67,8 @@ def _iadb_loop(model, x0, x_c, nb_step, scheduler_alpha, scheduler_gamma, schedu
         use_gamma = out_channel == 2 * Cc
     else:
         use_gamma = False
-    t_in, da, dg = step_tables(nb_step, scheduler_alpha, scheduler_gamma, scheduler_params, alpha_param)
+    t_in, da, dg = tables if tables is not None else \
+        step_tables(nb_step, scheduler_alpha, scheduler_gamma, scheduler_params, alpha_param)
     mask = _snap_mask(nb_step, train_or_test, log_freq)
     x = x0.detach().to(torch.float32).contiguous().clone()
     core = unwrap(model)
@@ -114,11 +115,13 @@ def _iadb_loop(model, x0, x_c, nb_step, scheduler_alpha, scheduler_gamma, schedu
 
 @torch.no_grad()
 def sample_iadb(model, x0, nb_step, scheduler_gamma, scheduler_params, out_channel, noise_type, train_or_test,
-                scheduler_alpha='linear', log_freq=1):
+                scheduler_alpha='linear', log_freq=1, alpha_param=0.02):
     """utils.sample_iadb (utils.py:179).  Returns (x, x_all, mean_forward_time) in 'test' mode and x
-    otherwise.  ``log_freq`` (extra, default = utils.py's 1) selects iadb_bn.py's cadence of 25."""
+    otherwise.  ``log_freq`` (extra, default = utils.py's 1) selects iadb_bn.py's cadence of 25;
+    ``alpha_param`` is the sigmoid start / cosine tau of a non-linear ``scheduler_alpha`` -- iadb_bn.py passes
+    ``opt.scheduler_param`` there (iadb_bn.py:115,131)."""
     x, x_all, ft = _iadb_loop(model, x0, None, nb_step, scheduler_alpha, scheduler_gamma, scheduler_params,
-                              out_channel, noise_type, train_or_test, log_freq)
+                              out_channel, noise_type, train_or_test, log_freq, alpha_param)
     if train_or_test == 'test':
         return x, x_all, ft
     return x
@@ -126,10 +129,10 @@ def sample_iadb(model, x0, nb_step, scheduler_gamma, scheduler_params, out_chann
 
 @torch.no_grad()
 def sample_iadb_conditional(model, x0, x_c, nb_step, scheduler_gamma, scheduler_params, out_channel, noise_type,
-                            train_or_test, scheduler_alpha='linear', log_freq=25):
+                            train_or_test, scheduler_alpha='linear', log_freq=25, alpha_param=0.02):
     """iadb_bn.sample_iadb_conditional (iadb_bn.py:384): model(cat([x, x_c], 1), alpha)."""
     x, x_all, _ = _iadb_loop(model, x0, x_c, nb_step, scheduler_alpha, scheduler_gamma, scheduler_params,
-                             out_channel, noise_type, train_or_test, log_freq)
+                             out_channel, noise_type, train_or_test, log_freq, alpha_param)
     if train_or_test == 'test':
         return x, x_all
     return x

@@ -118,6 +118,8 @@ class IADBScheduler(_ConfigIO):
         self.num_inference_steps = num_inference_steps
 
     def _coeffs(self, timestep):
+        # the reference forms alpha = (t+1)/n and alpha_next = t/n as Python floats (double precision) and multiplies
+        # the fp32 tensor by their difference (:95-117): one rounding, of the double difference
         n = self.num_inference_steps
         a, an = (timestep + 1) / n, timestep / n
         return np.float32(a - an), np.float32(a - an)       # gamma == alpha here (:95-99)
@@ -156,5 +158,9 @@ class IADBScheduler(_ConfigIO):
         n = self.num_inference_steps
         oc = self.out_channels
         nt = self.noise_type
-        out, _, _ = _iadb_loop(model, x, None, n, "linear", "linear", (1.0, 0.0, 3.0), oc, nt, "train", 1)
+        # step tables in double precision, as step() forms them: bit-identical to calling step() n times
+        t_in = np.array([(n - 1 - s + 1) / n for s in range(n)], dtype=np.float32)
+        d = np.array([np.float32((n - 1 - s + 1) / n - (n - 1 - s) / n) for s in range(n)], dtype=np.float32)
+        out, _, _ = _iadb_loop(model, x, None, n, "linear", "linear", (1.0, 0.0, 3.0), oc, nt, "train", 1,
+                               tables=(t_in, d, d.copy()))
         return out

@@ -172,6 +172,9 @@ class UNet2DModel(nn.Module):
         self._engine = None
         self._engine_key = None
 
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        return super().load_state_dict(convert_deprecated_attention_keys(state_dict), strict=strict, **kw)
+
     # ------------------------------------------------------------------ engine management
     def _param_version(self):
         return tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
@@ -236,6 +239,11 @@ class UNet2DModel(nn.Module):
         self._engine, self._engine_key = h, (key, max_batch)
         return h
 
+    def engine_ops(self, B, res, device):
+        """[(kernel, label, flops_per_sample)] of one forward at batch ``B`` (bndm_unet_op_info): which kernel
+        variants this configuration launches -- tile sizes are chosen from the handle's batch size."""
+        return engine_ops(self._ensure_engine(B, res, device))
+
     # ------------------------------------------------------------------ diffusers-style API
     def _timesteps(self, timestep, B, device):
         t = timestep
@@ -294,6 +302,37 @@ class UNet2DModel(nn.Module):
             sd = torch.load(os.path.join(directory, "diffusion_pytorch_model.bin"), map_location="cpu")
         model.load_state_dict(sd)
         return model
+
+
+_DEPRECATED_ATTN_KEYS = ((".query.", ".to_q."), (".key.", ".to_k."), (".value.", ".to_v."), (".proj_attn.", ".to_out.0."))
+
+
+def convert_deprecated_attention_keys(state_dict):
+    """Checkpoints written by diffusers < 0.18 (e.g. stabilityai/sd-vae-ft-mse, google/ddpm-*) store an attention
+    block as ``query / key / value / proj_attn`` -- sometimes as 1x1 convolutions [C, C, 1, 1] -- where current
+    diffusers (and this module tree) use ``to_q / to_k / to_v / to_out.0`` Linear weights [C, C].  diffusers renames
+    them on load (the reference relies on that at latent_iadb_bn_diffusers.py:70); do the same here."""
+    out = {}
+    for k, v in state_dict.items():
+        nk = k
+        if ".attentions." in k or ".attention." in k:
+            for old, new in _DEPRECATED_ATTN_KEYS:
+                nk = nk.replace(old, new)
+            if nk.endswith(".weight") and any(t in nk for t in (".to_q.", ".to_k.", ".to_v.", ".to_out.0.")) \
+                    and getattr(v, "dim", lambda: 0)() == 4 and v.shape[-1] == 1 and v.shape[-2] == 1:
+                v = v[:, :, 0, 0]
+        out[nk] = v
+    return out
+
+
+def engine_ops(handle):
+    lib = _lib.load()
+    kern, label, fl = C.create_string_buffer(64), C.create_string_buffer(200), C.c_double()
+    ops = []
+    for i in range(lib.bndm_unet_num_ops(handle)):
+        _lib.check(lib.bndm_unet_op_info(handle, i, kern, 64, label, 200, C.byref(fl)), "bndm_unet_op_info")
+        ops.append((kern.value.decode(), label.value.decode(), fl.value))
+    return ops
 
 
 def unwrap(model):

@@ -103,8 +103,9 @@ class AutoencoderKL(nn.Module):
 
     # checkpoints of the full autoencoder also carry encoder.* / quant_conv.*: not needed for decode
     def load_state_dict(self, state_dict, strict=True):
+        from .unet import convert_deprecated_attention_keys
         sd = {k: v for k, v in state_dict.items() if k.startswith(("decoder.", "post_quant_conv."))}
-        return super().load_state_dict(sd, strict=strict)
+        return super().load_state_dict(convert_deprecated_attention_keys(sd), strict=strict)
 
     def half(self):                      # vae.half() in user code: storage is 16-bit inside the engine already
         return self

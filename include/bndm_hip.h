@@ -133,6 +133,14 @@ int  bndm_unet_load_param(bndm_unet *h, const char *name, const float *host_data
 /* all parameters present -> pack derived tables; must precede forward */
 int  bndm_unet_finalize(bndm_unet *h);
 
+/* The launch list of one forward, fixed at finalize (it depends on max_batch: tile variants are chosen for the
+ * handle's batch size).  kernel: family + tile variant ("conv_tap9<TH=16>", "conv_igemm", "gn_small", ...); label: the
+ * layer it computes (diffusers module path).  Lets a test assert which kernels a configuration runs; no reference
+ * counterpart (the reference's launch list is whatever eager PyTorch dispatches at iadb_bn.py:319). */
+int  bndm_unet_num_ops(const bndm_unet *h);
+int  bndm_unet_op_info(const bndm_unet *h, int index, char *kernel, size_t kernel_len, char *label,
+                       size_t label_len, double *flops_per_sample);
+
 /* sample [B,Cin,H,W] f32 (device), timesteps [B] f32 (device), out [B,Cout,H,W] f32 (device) */
 int  bndm_unet_forward(bndm_unet *h, const float *sample, const float *timesteps, float *out,
                        int B, void *stream);

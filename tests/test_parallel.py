@@ -56,3 +56,29 @@ def test_gather_images_world2_gloo(total):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_bench_self_launch_world2_dry_run():
+    """`python bench.py --gpus 2` with no launcher starts its own ranks: dry run on CPU / gloo --
+    two ranks rendezvous on 127.0.0.1, barrier, max-over-ranks, ONE JSON line from rank 0 carrying n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-cpu"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["dry_run"] is True
+    assert lines[0]["elapsed"] >= 0.02                                   # the slower rank's time (max over ranks)
+
+
+def test_bench_refuses_a_mislabelled_world():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-cpu"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "refusing" in (out.stderr + out.stdout)
