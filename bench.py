@@ -297,11 +297,11 @@ def main():
                                    B, 3, C.byref(prof), _lib.current_stream_ptr())
         _lib.check(rc, "bndm_unet_profile")
         from bndm_amd.unet import engine_ops
-        dom = sorted({k for k, _, _ in engine_ops(h) if k.startswith("conv_tap9<TH=16")})
-        kernel_tag = dom[0] if dom else "conv_tap9"
+        dom = sorted({k for k, _, _ in engine_ops(h) if k.startswith("conv_t32<TH=16")})
+        kernel_tag = dom[0] if dom else "conv_t32"
         achieved = prof.dom_flops / (prof.ms_dom * 1e-3) / 1e12 if prof.ms_dom > 0 else 0.0
         conv_all = prof.conv_flops / (prof.ms_conv * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": f"{kernel_tag} (GroupNorm+SiLU fused 3x3 conv, 256-pixel tiles)",
+        roof = {"bound": "mfma", "kernel": f"{kernel_tag} (GroupNorm+SiLU fused 3x3 conv, 256-pixel x 128-channel tiles, two workgroups per CU)",
                 "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F16_TFLOPS, 4),
                 # HBM bytes per launch: rocprofv3 PMC passes of this very build (tools/pmc_traffic.py), else null

@@ -1,0 +1,824 @@
+// conv_t32: the fused GroupNorm+SiLU 3x3 convolution of the FLOP-dominant UNet layers (H >= 16), built so that TWO
+// workgroups are resident per CU.
+//
+// One workgroup = 256 threads = 4 waves (one per SIMD) and at most 80 KiB of LDS; it computes a TH x 16 pixel tile of
+// one sample x 128 output channels.  Wave w owns TH/4 pixel rows of the tile and ALL 128 channels (64 x 128 wave tile:
+// 4 x 2 MFMA tiles of 32x32, six ds_read_b128 per eight MFMAs).  K runs over 32-channel chunks of up to 4 segments
+// (concatenated inputs, nearest-2x upsampled inputs, a fused 1x1 conv_shortcut): per chunk the (TH+2) x 18 halo patch is
+// brought in ONCE by LDS-DMA (64 B per pixel), normalised in place (GroupNorm scale/shift + SiLU) by the thread that
+// issued each piece, and read by all nine taps; the [128][32] weight tile of every tap streams through a 4-slot ring
+// three K-steps ahead.  Weights are packed tile-contiguous and pre-swizzled on the host (pack_weights_t32), so a K-step's
+// tile is one linear 8 KiB read.
+//
+// Why two workgroups per CU: the launch-wide bursts of one-workgroup-per-CU kernels (every CU in its prologue, then
+// every CU in its epilogue) leave the MFMA pipe idle for a third of each launch, and inside the loop all waves of a
+// workgroup issue their LDS-DMA right behind the same barrier.  With two independent workgroups per CU -- one wave of
+// each on every SIMD -- one's prologue / epilogue / DMA issue / barrier wait is the other's MFMA time.
+//
+// LDS patch layout: pixel p = py * 18 + px at byte 64 p, its four 16-byte channel groups XOR-ed with a 2-bit key
+// g(py & 1, px) found by search (t32_patch_key) such that every 16-lane group of every ds_read_b128 fragment read hits
+// 16 distinct bank quads for all nine tap shifts.  LDS-DMA destinations are lane-linear, so the permutation sits on the
+// source address (which channel group a lane fetches) and on the read address.
+#include "unet_kernels.hpp"
+#include "unet_types.hpp"
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace bndm {
+
+// key of patch pixel (py, px): 2 bits per px, one 36-bit word per row parity
+__host__ __device__ constexpr int t32_patch_key(int py, int px) {
+    return (int)((((py & 1) ? 0x2479cc7f2ull : 0x712c992a7ull) >> (2 * px)) & 3ull);
+}
+
+namespace {
+
+template <int N> struct IC {
+    static constexpr int value = N;
+};
+
+// patch DMA rounds issued after the barrier of tap t: ceil(nround / 3) per tap over taps 0..2; t is taken modulo 9
+constexpr int rounds_per_tap(int nround) { return (nround + 2) / 3; }
+constexpr int rounds_at_tap(int nround, int t) {
+    t = ((t % 9) + 9) % 9;
+    const int rpt = rounds_per_tap(nround), left = nround - rpt * t;
+    return t > 2 ? 0 : (left >= rpt ? rpt : (left > 0 ? left : 0));
+}
+// DMAs a thread has issued after patch round r by the end of group G_s; nwp = weight pieces per thread and tile
+constexpr int dmas_after_round(int nround, int nwp, int r, int s) {
+    const int rpt = rounds_per_tap(nround), g = r / rpt;
+    int n = (rpt * g + rpt - 1 < nround - 1 ? rpt * g + rpt - 1 : nround - 1) - r;
+    for (int j = g + 1; j <= s; ++j) n += nwp + rounds_at_tap(nround, j);
+    return n;
+}
+
+typedef uint32_t u32x4t __attribute__((ext_vector_type(4)));
+
+constexpr int T32_MAX_CHUNKS = 32;
+constexpr int T32_SS_BYTES = 4096;           // scale/shift table [2][ssC] fp32, ssC <= 512
+
+// wave-uniform description of one 32-channel chunk of a segment
+struct Chunk {
+    const void *src;             // the segment's tensor
+    int bytes;                   // ... and its size
+    int soff;                    // chunk * 64 bytes
+    int C2;                      // bytes per source pixel
+    int up;                      // source at half resolution
+    int ssbase;                  // float offset of the chunk's scale row in the LDS table, or -1
+};
+
+// ABL: profiling switches (results are wrong when non-zero): 1 no MFMA, 2 no weight DMA, 4 no fragment reads,
+// 8 no in-loop patch DMA / normalisation, 16 no in-loop normalisation (DMA kept), 64 record s_memtime marks of
+// block 0 / chunk 1 into dbg[wave][tap][6]
+// stagger: workgroups 256..511 -- the second resident workgroup of every CU in the first dispatch round, as the
+// dispatcher is observed to fill the CUs (a speed assumption only) -- start `stagger` shader cycles late, so that the two
+// workgroups of a CU run out of phase: one's prologue / epilogue (HBM-bound, launch-wide bursts if everybody is in
+// step) falls into the other's MFMA time.  Later workgroups inherit the offset from the slot they take over.
+template <typename T, int TH, int ABL>
+__global__ __launch_bounds__(256, 2) void conv_t32(const FusedArgs a, const int tiles_x, const int tps, const int ntn,
+                                                   const int nsteps_w, const int stagger, unsigned *__restrict__ dbg) {
+    using v8 = typename TT<T>::v8;
+    using v4 = typename TT<T>::v4;
+    using v2 = typename TT<T>::v2;
+    constexpr int TW = 16, PW = TW + 2, PH = TH + 2;
+    constexpr int NT = 256, NW = 4;
+    constexpr int NPIECE = PH * PW * 4;                // 16-byte pieces per patch chunk
+    constexpr int NWP = (128 * 64) / (NT * 16);        // weight-tile pieces per thread (2)
+    constexpr int NROUND = (NPIECE + NT - 1) / NT;     // patch DMA rounds per chunk (the last one may be partial)
+    constexpr int NREMW = (NPIECE - (NROUND - 1) * NT + 63) / 64;    // waves with pieces in the last round
+    constexpr int PATCH_BYTES = (NROUND - 1) * NT * 16 + NREMW * 1024;
+    constexpr int BM = TH * TW;
+    constexpr int TM = TH / 8;                         // 32-pixel MFMA tiles per wave along M (2 rows x 16 columns each)
+    constexpr int TN = 4;
+    constexpr int WSTAGES = 4, W_BYTES = 128 * 64;
+    constexpr int OFF_W = 2 * PATCH_BYTES;
+    constexpr int OFF_SS = OFF_W + WSTAGES * W_BYTES;
+    constexpr int OFF_TAB = OFF_SS + T32_SS_BYTES;     // chunk descriptors, 16 B each
+    constexpr int OFF_BIAS = OFF_TAB + T32_MAX_CHUNKS * 16;   // 128 fp32: bias (+ time embedding) row of this tile
+    constexpr int OFF_DUMP = OFF_BIAS + 512;                  // dead slot: DMAs of waves / lanes without a piece
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63;
+    auto life = [&](int k) {                           // profiling aid: lifetime marks of two workgroups
+        if constexpr ((ABL & 64) != 0) {
+            if ((blockIdx.x == 0 || blockIdx.x == 700) && a.Ktot == 2304) {
+                const unsigned tm = (unsigned)__builtin_amdgcn_s_memtime();
+                if (tid == 0) dbg[216 + (blockIdx.x ? 16 : 0) + k] = tm;
+            }
+        }
+    };
+    life(0);
+    if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)stagger) __builtin_amdgcn_s_sleep(64);
+    }
+
+    // ---- tile id (XCD-aware: neighbouring tiles of a sample share halos and weights) ---------------
+    int tix;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        tix = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    tix = __builtin_amdgcn_readfirstlane(tix);
+    const int mt = tix / ntn, nt = tix - mt * ntn;
+    const int b = __builtin_amdgcn_readfirstlane(mt / tps), tin = __builtin_amdgcn_readfirstlane(mt - b * tps);
+    const int ty = tin / tiles_x, tx = tin - ty * tiles_x;
+    const int y0 = __builtin_amdgcn_readfirstlane(ty * TH), x0 = __builtin_amdgcn_readfirstlane(tx * TW);
+    const int n0 = __builtin_amdgcn_readfirstlane(nt * 128);
+    const int H = a.H, Wd = a.W;
+    const int lgH = 31 - __builtin_clz(H), lgW = 31 - __builtin_clz(Wd);
+
+    // ---- chunk descriptors of the whole K loop (3x3 chunks first, then the 1x1 ones), built once into LDS ----------
+    int nchunk9 = 0, nchunk1 = 0;           // 3x3 segments come first (checked by the launcher)
+#pragma unroll
+    for (int i = 0; i < CONV_MAX_SEG; ++i)
+        if (i < a.nseg) {
+            if (a.seg[i].taps == 9) nchunk9 += a.seg[i].C >> 5;
+            else nchunk1 += a.seg[i].C >> 5;
+        }
+    if (tid < nchunk9 + nchunk1) {
+        int rem = tid, si = 0, ci = 0;
+        bool found = false;
+#pragma unroll
+        for (int i = 0; i < CONV_MAX_SEG; ++i) {
+            const int nci = i < a.nseg ? a.seg[i].C >> 5 : 0;
+            if (!found && rem < nci) {
+                si = i;
+                ci = rem;
+                found = true;
+            }
+            rem -= nci;
+        }
+        FusedSeg sg = a.seg[0];
+        if (si == 1) sg = a.seg[1];
+        if (si == 2) sg = a.seg[2];
+        if (si == 3) sg = a.seg[3];
+        const uint64_t u = (uint64_t)sg.src;
+        u32x4t e;
+        e[0] = (uint32_t)u;
+        e[1] = (uint32_t)(u >> 32);
+        e[2] = (uint32_t)(sg.C * 2) | ((uint32_t)(ci * 64) << 12) | ((uint32_t)sg.up << 31);
+        e[3] = (uint32_t)(sg.ss_off >= 0 ? sg.ss_off + ci * 32 : -1);
+        *reinterpret_cast<u32x4t *>(smem + OFF_TAB + tid * 16) = e;
+    }
+    auto load_chunk = [&](int n) {
+        const u32x4t e = *reinterpret_cast<const u32x4t *>(smem + OFF_TAB + n * 16);
+        Chunk c;
+        const uint32_t plo = __builtin_amdgcn_readfirstlane(e[0]), phi = __builtin_amdgcn_readfirstlane(e[1]);
+        c.src = (const void *)(((uint64_t)phi << 32) | plo);
+        const uint32_t m = __builtin_amdgcn_readfirstlane(e[2]);
+        c.C2 = m & 0xfff;
+        c.soff = (m >> 12) & 0xfff;
+        c.up = m >> 31;
+        c.ssbase = __builtin_amdgcn_readfirstlane(e[3]);
+        c.bytes = a.B * (c.up ? (H >> 1) * (Wd >> 1) : H * Wd) * c.C2;
+        return c;
+    };
+
+    // ---- patch piece descriptors (independent of the chunk) ----------------------------------------
+    // piece = round * 256 + tid = (patch pixel, physical 16-byte slot); slot j of pixel (py, px) holds channel group
+    // j ^ key(py, px)
+    int p_full[NROUND];                                // source pixel index of the piece, -1: padding
+    int p_pack = 0;                                    // per round: bits 3r, 3r+1 source channel group, bit 3r+2 valid
+#pragma unroll
+    for (int r = 0; r < NROUND; ++r) {
+        const int piece = r * NT + tid;
+        const int pc = piece < NPIECE ? piece : NPIECE - 1;
+        const int pp = pc >> 2, pch = pc & 3;
+        const int pyy = pp / PW, pxx = pp - pyy * PW;
+        const int iy = y0 - 1 + pyy, ix = x0 - 1 + pxx;
+        const bool ok = piece < NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)Wd;
+        p_full[r] = ok ? (b * H + iy) * Wd + ix : -1;                      // -1: out-of-range offset -> zeros
+        p_pack |= ((pch ^ t32_patch_key(pyy, pxx)) | (ok ? 4 : 0)) << (3 * r);
+    }
+    struct Piece {
+        int pix, lc;
+        bool valid;
+    };
+    auto piece_of = [&](int r) { return Piece{p_full[r], (p_pack >> (3 * r)) & 3, ((p_pack >> (3 * r + 2)) & 1) != 0}; };
+    auto patch_dma = [&](auto rc, const Chunk &c, int buf) {
+        constexpr int r = decltype(rc)::value;
+        const Piece pc = piece_of(r);
+        int pix = pc.pix;
+        if (c.up) {                                    // nearest-2x source: H and W are powers of two
+            const int ix = pix & (Wd - 1), iy = (pix >> lgW) & (H - 1), bb = pix >> (lgW + lgH);
+            pix = pix < 0 ? -1 : ((((bb << (lgH - 1)) + (iy >> 1)) << (lgW - 1)) + (ix >> 1));
+        }
+        const unsigned voff = (unsigned)(pix * c.C2 + (pc.lc << 4));
+        char *dst = smem + ((r < NROUND - 1 || w < NREMW) ? buf * PATCH_BYTES + r * (NT * 16) + w * 1024 : OFF_DUMP);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(uniform_rsrc(c.src, c.bytes), (lds_ptr_t)dst, 16, voff,
+                                                 __builtin_amdgcn_readfirstlane(c.soff), 0, 0);
+    };
+    // GroupNorm scale/shift + SiLU applied in place to this thread's own piece of a round (the reference pads
+    // AFTER the activation: padding / tail pieces are rewritten unchanged, i.e. stay zero)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const float *ssL = reinterpret_cast<const float *>(smem + OFF_SS);
+    auto xf_begin = [&](auto rc, int buf, u32x4 &x) {
+        constexpr int r = decltype(rc)::value;
+        x = *reinterpret_cast<const u32x4 *>(smem + buf * PATCH_BYTES + r * (NT * 16) + tid * 16);
+    };
+    auto xf_end = [&](auto rc, int buf, const u32x4 &x) {
+        constexpr int r = decltype(rc)::value;
+        *reinterpret_cast<u32x4 *>(smem + buf * PATCH_BYTES + r * (NT * 16) + tid * 16) = x;
+    };
+    auto norm2 = [&](unsigned xq, float s0, float s1, float h0, float h1, bool valid) {
+        const v2 in = __builtin_bit_cast(v2, xq);
+        v2 o;
+        const float f0 = fmaf((float)in[0], s0, h0), f1 = fmaf((float)in[1], s1, h1);
+        o[0] = (T)(f0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f0)));
+        o[1] = (T)(f1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f1)));
+        return valid ? __builtin_bit_cast(unsigned, o) : xq;
+    };
+    // half h (0 / 1) of round r of chunk c: dwords 2h, 2h+1 of the piece = channels 4h .. 4h+3 of its group
+    auto xf_half = [&](auto rc, auto hc, const Chunk &c, u32x4 &x) {
+        constexpr int r = decltype(rc)::value, h = decltype(hc)::value;
+        const Piece pc = piece_of(r);
+        const bool valid = pc.valid;
+        const float *sc = ssL + c.ssbase + pc.lc * 8 + 4 * h;
+        const f32x4 s4 = *reinterpret_cast<const f32x4 *>(sc), h4 = *reinterpret_cast<const f32x4 *>(sc + a.ssC);
+        x[2 * h] = norm2(x[2 * h], s4[0], s4[1], h4[0], h4[1], valid);
+        x[2 * h + 1] = norm2(x[2 * h + 1], s4[2], s4[3], h4[2], h4[3], valid);
+    };
+    auto xf_owner = [&](int r) { return r < NROUND - 1 || w < NREMW; };    // wave-uniform
+
+    // ---- weight tiles: [128 rows][64 B] per K-step, packed per (n-tile, step) as one linear 8 KiB block ----------
+    const __amdgpu_buffer_rsrc_t wrs =
+        uniform_rsrc((const char *)a.Wgt + (size_t)nt * nsteps_w * W_BYTES, nsteps_w * W_BYTES);
+    auto w_issue = [&](int slot, int step) {
+        char *base = smem + OFF_W + slot * W_BYTES + w * 1024;
+        const int so = __builtin_amdgcn_readfirstlane(step * W_BYTES);
+#pragma unroll
+        for (int i = 0; i < NWP; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(base + i * (NT * 16)), 16,
+                                                     (unsigned)(tid * 16 + i * (NT * 16)), so, 0, 0);
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int q = l & 31, kh = l >> 5;
+    const int row_base = w * (TH / NW);
+    const int lr = q >> 4, lcx = q & 15;
+
+    // ---- fragment addresses ---------------------------------------------------------------------------
+    // weights: row q of the tile (+ 32 i), slot (2 ks + kh) ^ ((q >> 2) & 3).  patch: pixel (row_base + 2j + lr + ky,
+    // lcx + kx), slot (2 ks + kh) ^ key(row parity, lcx + kx); ky = 0 and 2 share the parity, so they differ by an
+    // immediate.
+    // The second k16 slice (ks = 1) flips bit 1 of the slot index, i.e. bit 5 of the byte address: one v_xor per
+    // fragment base instead of a second set of address registers.
+    int wa, pa[2][3];
+    wa = OFF_W + q * 64 + ((kh ^ ((q >> 2) & 3)) << 4);
+#pragma unroll
+    for (int kyp = 0; kyp < 2; ++kyp)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+            pa[kyp][kx] = ((row_base + lr + kyp) * PW + lcx + kx) * 64 +
+                          ((kh ^ t32_patch_key(row_base + lr + kyp, lcx + kx)) << 4);
+    // Weight fragments live in ONE register set that is refilled in place: fa[i] is read again (for the next phase) right
+    // behind the MFMAs that consumed it, six or more MFMAs before its next use.  Patch fragments are used by every
+    // MFMA of a phase and are double-buffered.
+    v8 fa[TN], fb[2][TM];
+    auto read_b = [&](auto tc, auto kc) {
+        constexpr int t = decltype(tc)::value, ks = decltype(kc)::value;
+        constexpr int ky = t / 3, kx = t % 3;
+        if (ABL & 4) return;
+        const int pb = pa[ky & 1][kx] ^ (ks << 5);
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+            fb[ks][j] = *reinterpret_cast<const v8 *>(smem + pb + ((ky & 2) * PW + 2 * j * PW) * 64);
+    };
+    auto read_a = [&](auto kc, int i) {
+        constexpr int ks = decltype(kc)::value;
+        if (ABL & 4) return;
+        fa[i] = *reinterpret_cast<const v8 *>(smem + (wa ^ (ks << 5)) + i * 2048);
+    };
+    // one phase: the MFMAs of k16 slice `kcur` (operands in fa, fb[kcur]) and the reads of slice (tnext, knext)
+    auto mma_refill = [&](auto kcur, auto tnext, auto knext) {
+        constexpr int ks = decltype(kcur)::value;
+        read_b(tnext, knext);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            if (ABL & 1) {
+                asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+                for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(fb[ks][j]));
+            } else {
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = TT<T>::mfma(fa[i], fb[ks][j], acc[i][j]);
+            }
+            read_a(knext, i);
+        }
+    };
+
+    // ---- prologue -------------------------------------------------------------------------------------
+    // scale/shift table (one 16-byte piece per thread, zeros past its end), patch of chunk 0, weight tiles of
+    // steps 0..3 -- all by LDS-DMA, so they retire in issue order and one counted wait separates them
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // chunk table visible
+    asm volatile("" ::: "memory");
+    Chunk cur = load_chunk(0);
+    Chunk nxt = cur;
+    {
+        const __amdgpu_buffer_rsrc_t srs =
+            uniform_rsrc(a.ss ? a.ss + (size_t)b * 2 * a.ssC : (const float *)a.zeros, a.ss ? 2 * a.ssC * 4 : 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_ptr_t)(smem + OFF_SS + w * 1024), 16, (unsigned)(tid * 16), 0,
+                                                 0, 0);
+        // the tile's additive row (the launcher passes bias OR the time-embedding row, which has the bias folded in):
+        // 32 pieces by the first lanes of wave 0 (its other lanes and the other waves read zeros into the dead slot,
+        // which starts right behind the row)
+        const float *row = a.temb ? a.temb + (size_t)b * a.temb_bstride + a.temb_off + n0 : a.bias ? a.bias + n0 : nullptr;
+        const __amdgpu_buffer_rsrc_t brs = uniform_rsrc(row ? row : (const float *)a.zeros, row ? 512 : 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lds_ptr_t)(smem + (w == 0 ? OFF_BIAS : OFF_DUMP)), 16,
+                                                 (unsigned)(tid * 16), 0, 0, 0);
+    }
+    const int nstep9 = nchunk9 * 9;
+    if (nchunk9 > 0) {
+        auto issue_all = [&](auto self, auto rc) {
+            constexpr int r = decltype(rc)::value;
+            if constexpr (r < NROUND) {
+                patch_dma(rc, cur, 0);
+                self(self, IC<r + 1>{});
+            }
+        };
+        issue_all(issue_all, IC<0>{});
+        w_issue(0, 0);
+        w_issue(1, 1);
+        w_issue(2, 2);
+        w_issue(3, 3);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NWP) : "memory");      // table + own patch pieces landed
+        __builtin_amdgcn_s_barrier();                         // ... in every wave (the table is shared)
+        asm volatile("" ::: "memory");
+        if (!(ABL & 8) && cur.ssbase >= 0) {
+            auto xf_all = [&](auto self, auto rc) {
+                constexpr int r = decltype(rc)::value;
+                if constexpr (r < NROUND) {
+                    if (xf_owner(r)) {
+                        u32x4 x;
+                        xf_begin(rc, 0, x);
+                        xf_half(rc, IC<0>{}, cur, x);
+                        xf_half(rc, IC<1>{}, cur, x);
+                        xf_end(rc, 0, x);
+                    }
+                    self(self, IC<r + 1>{});
+                }
+            };
+            xf_all(xf_all, IC<0>{});
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (nchunk9 > 1) nxt = load_chunk(1);
+    life(1);
+
+    // ---- 3x3 chunks -----------------------------------------------------------------------------------
+    // Step t of a chunk (tap t) runs two k16 phases of eight MFMAs; the fragments of a phase are read while the MFMAs
+    // of the previous one run (two register sets).  Barrier B_t sits between the phases.  Every wave reaches it with
+    // lgkmcnt(0), i.e. with all its reads of weight tile t (and, at t = 8, its normalisation writes) complete, and with
+    // tile t+1 landed (vmcnt), so after B_t tile t+1 (at t = 8 also the next chunk's patch) may be read and the DMA group
+    //     G_t = [ weight tile t+4 -> the ring slot of tile t (2 pieces), patch rounds of the next chunk into the other
+    //             patch buffer (t = 0, 1, 2) ]
+    // is issued: every tile has three full steps to land.  vmcnt before B_t certifies the tile issued in G_(t-3);
+    // younger are the patch pieces of G_(t-3) and all of G_(t-2), G_(t-1):
+    //     N_t = np(t-3) + 2 + np(t-2) + 2 + np(t-1).
+    // Patch round r is normalised in place by its issuing thread between B_s and B_(s+1), s = 3 + r, in two halves that
+    // ride in the shadow of the 16 MFMAs of that window; the window opens with its own counted wait
+    // (dmas_after_round) for that piece, normally long satisfied; B_8 publishes the patch.
+    int slot = 0;                                        // ring slot of the current step's weight tile
+    int pbuf = 0;                                        // patch buffer of the current chunk
+    int wstep = 0;                                       // global K-step index of the current step
+    if (nchunk9 > 0) {
+        read_b(IC<0>{}, IC<0>{});
+#pragma unroll
+        for (int i = 0; i < TN; ++i) read_a(IC<0>{}, i);
+    }
+    constexpr int NFULL = NROUND - (NREMW < NW ? 1 : 0);   // rounds in which every wave owns pieces
+    static_assert(NFULL <= 5, "normalisation schedule: one full round per window of steps 3..7 (+ a partial one)");
+    auto chunk_body = [&](auto doxc, const int c) __attribute__((always_inline)) {
+        constexpr bool DOX = decltype(doxc)::value != 0 && !(ABL & 8) && !(ABL & 16);
+        u32x4 xa = {0u, 0u, 0u, 0u};                           // round in flight
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, ha = {0.f, 0.f, 0.f, 0.f};
+        // window of step s (3..7): position 0 = second phase of step s, position 1 = first phase of step s+1; it
+        // normalises full round s-3, four channels per position
+        // xf_pre: LDS reads of a position, issued at the end of the phase before it (they return during the barrier wait)
+        auto xf_pre = [&](auto sc, auto pc) {
+            constexpr int s = decltype(sc)::value, p = decltype(pc)::value;
+            constexpr int r = s >= 3 && s <= 7 && s - 3 < NFULL ? s - 3 : -1;
+            if constexpr (DOX && r >= 0) {
+                if constexpr (p == 0) {
+                    // own piece landed?  (G_s is issued later in this phase: count up to G_(s-1))
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dmas_after_round(NROUND, NWP, r, s - 1)) : "memory");
+                    xf_begin(IC<r>{}, pbuf ^ 1, xa);
+                }
+                const float *sc4 = ssL + nxt.ssbase + piece_of(r).lc * 8 + 4 * p;
+                sa = *reinterpret_cast<const f32x4 *>(sc4);
+                ha = *reinterpret_cast<const f32x4 *>(sc4 + a.ssC);
+            }
+        };
+        auto xf_math = [&](auto sc, auto pc) {
+            constexpr int s = decltype(sc)::value, p = decltype(pc)::value;
+            constexpr int r = s >= 3 && s <= 7 && s - 3 < NFULL ? s - 3 : -1;
+            if constexpr (DOX && r >= 0) {
+                const bool valid = piece_of(r).valid;
+                xa[2 * p] = norm2(xa[2 * p], sa[0], sa[1], ha[0], ha[1], valid);
+                xa[2 * p + 1] = norm2(xa[2 * p + 1], sa[2], sa[3], ha[2], ha[3], valid);
+                if constexpr (p == 1) xf_end(IC<r>{}, pbuf ^ 1, xa);
+            }
+        };
+        // the partial last round (pieces of waves < NREMW only): in one go at the end of the last window (the
+        // registers of the finished round are free again)
+        auto xf_tail = [&](auto sc, auto pc) {
+            constexpr int s = decltype(sc)::value, p = decltype(pc)::value;
+            if constexpr (DOX && NREMW < NW && s == 7 && p == 1) {
+                constexpr int r = NROUND - 1;
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dmas_after_round(NROUND, NWP, r, s)) : "memory");
+                if (w < NREMW) {
+                    xf_begin(IC<r>{}, pbuf ^ 1, xa);
+                    xf_half(IC<r>{}, IC<0>{}, nxt, xa);
+                    xf_half(IC<r>{}, IC<1>{}, nxt, xa);
+                    xf_end(IC<r>{}, pbuf ^ 1, xa);
+                }
+            }
+        };
+        // MFMAs of a phase with everything else of the phase issued in their shadow: per MFMA one fragment read (the
+        // next phase's operands), one LDS-DMA while there are any, and a share of the normalisation arithmetic.  Without
+        // the interleave the compiler issues the six reads (and the DMAs) first and the MFMA pipe sits idle meanwhile.
+        auto phase = [&](auto kcur, auto tnext, auto knext, auto sc, auto pc, auto nvm) {
+            constexpr int s = decltype(sc)::value, NVMEM = decltype(nvm)::value;
+            constexpr int r = s >= 3 && s <= 7 && s - 3 < NFULL ? s - 3 : -1;
+            // the phase is its own scheduling region: the group pattern below must only see this phase's instructions
+            __builtin_amdgcn_sched_barrier(0);
+            mma_refill(kcur, tnext, knext);
+            xf_math(sc, pc);
+            if constexpr (!(ABL & 1) && !(ABL & 4) && !(ABL & 32)) {
+                constexpr int NV = DOX && r >= 0 ? 11 : 2;
+                __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);                             // patch fragments first
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);                         // MFMAs of weight tile i
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          // its refill
+                    if (i < NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // 1 LDS-DMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                         // VALU in the shadow
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mark = [&](int t, int k) {
+            if constexpr ((ABL & 64) != 0) {
+                if (blockIdx.x == 0 && c == 1) {
+                    const unsigned tm = (unsigned)__builtin_amdgcn_s_memtime();
+                    if (l == 0) dbg[(w * 9 + t) * 6 + k] = tm;
+                }
+            }
+        };
+        auto step = [&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            mark(t, 0);
+            // first phase: MFMAs of (tap t, k 0..15); reads of (tap t, k 16..31); then the LDS reads of the normalisation
+            // slice that rides under the second phase, so that they return during the wait / barrier
+            phase(IC<0>{}, tc, IC<1>{}, IC<t - 1>{}, IC<1>{}, IC<0>{});
+            xf_tail(IC<t - 1>{}, IC<1>{});
+            xf_pre(tc, IC<0>{});
+            // advance the weight ring (and, at the last tap, the chunk) before the reads of the next step
+            {
+                const int d = slot == WSTAGES - 1 ? -(WSTAGES - 1) * W_BYTES : W_BYTES;
+                wa += d;
+                slot = (slot + 1) & (WSTAGES - 1);
+                ++wstep;
+            }
+            if constexpr (t == 8) {
+                const int d = pbuf ? -PATCH_BYTES : PATCH_BYTES;
+#pragma unroll
+                for (int kyp = 0; kyp < 2; ++kyp)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) pa[kyp][kx] += d;
+                pbuf ^= 1;
+                cur = nxt;
+                nxt = load_chunk(c + 2 < nchunk9 ? c + 2 : nchunk9 - 1);
+            }
+            constexpr int N = rounds_at_tap(NROUND, t - 3) + NWP + rounds_at_tap(NROUND, t - 2) + NWP +
+                              rounds_at_tap(NROUND, t - 1);
+            mark(t, 1);
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+            mark(t, 2);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            mark(t, 3);
+            // second phase: DMA group G_t; MFMAs of (tap t, k 16..31); reads of (tap t+1, k 0..15)
+            if (!(ABL & 2)) {
+                // tile of step t+4 (wstep was advanced: it is the index of step t+1)
+                const int ws = wstep + 3 < nstep9 ? wstep + 3 : nstep9 - 1;
+                w_issue((slot + 3) & (WSTAGES - 1), ws);         // slot was advanced: the slot of tile t
+            }
+            if constexpr (rounds_at_tap(NROUND, t) > 0) {
+                if (!(ABL & 8)) {
+                    constexpr int R0 = rounds_per_tap(NROUND) * t, NR = rounds_at_tap(NROUND, t);
+                    static_assert(NR <= 2, "at most two patch rounds per tap");
+                    patch_dma(IC<R0>{}, nxt, pbuf ^ 1);
+                    if constexpr (NR > 1) patch_dma(IC<(NR > 1 ? R0 + 1 : 0)>{}, nxt, pbuf ^ 1);
+                }
+            }
+            phase(IC<1>{}, IC<(t + 1) % 9>{}, IC<0>{}, tc, IC<0>{}, IC<NWP + rounds_at_tap(NROUND, t)>{});
+            xf_pre(tc, IC<1>{});                                 // for the first phase of the next step
+            mark(t, 4);
+        };
+        step(IC<0>{});
+        step(IC<1>{});
+        step(IC<2>{});
+        step(IC<3>{});
+        step(IC<4>{});
+        step(IC<5>{});
+        step(IC<6>{});
+        step(IC<7>{});
+        step(IC<8>{});
+    };
+    if (nchunk9 > 0) {
+        if (cur.ssbase >= 0) {
+            for (int c = 0; c + 1 < nchunk9; ++c) chunk_body(IC<1>{}, c);
+        } else {
+            for (int c = 0; c + 1 < nchunk9; ++c) chunk_body(IC<0>{}, c);
+        }
+        chunk_body(IC<0>{}, nchunk9 - 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    life(2);
+    // ---- 1x1 chunks (raw centre pixels; patch + weight tile of chunk n+1 fly while chunk n multiplies) ----
+    if (nchunk1 > 0) {
+        auto issue1 = [&](const Chunk &c, int buf, int step) {
+            auto issue_all = [&](auto self, auto rc) {
+                constexpr int r = decltype(rc)::value;
+                if constexpr (r < NROUND) {
+                    patch_dma(rc, c, buf);
+                    self(self, IC<r + 1>{});
+                }
+            };
+            issue_all(issue_all, IC<0>{});
+            w_issue(buf, step);
+        };
+        issue1(load_chunk(nchunk9), 0, nstep9);
+        for (int n = 0; n < nchunk1; ++n) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (n + 1 < nchunk1) issue1(load_chunk(nchunk9 + n + 1), (n + 1) & 1, nstep9 + n + 1);
+            const int buf = n & 1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int wb = OFF_W + buf * W_BYTES + q * 64 + (((2 * ks + kh) ^ ((q >> 2) & 3)) << 4);
+                const int pb = buf * PATCH_BYTES + ((row_base + lr + 1) * PW + lcx + 1) * 64 +
+                               (((2 * ks + kh) ^ t32_patch_key(row_base + lr + 1, lcx + 1)) << 4);
+                v8 ga[TN], gb[TM];
+#pragma unroll
+                for (int i = 0; i < TN; ++i) ga[i] = *reinterpret_cast<const v8 *>(smem + wb + i * 2048);
+#pragma unroll
+                for (int j = 0; j < TM; ++j) gb[j] = *reinterpret_cast<const v8 *>(smem + pb + 2 * j * PW * 64);
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) acc[i][j] = TT<T>::mfma(ga[i], gb[j], acc[i][j]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    life(3);
+    // ---- epilogue 1: bias + time embedding -> 16-bit tile in LDS ([BM][128 ch], swizzled) ---------------
+    char *stg = smem;
+    f32x4 addv[TN][4];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            addv[i][g] = *reinterpret_cast<const f32x4 *>(smem + OFF_BIAS + (i * 32 + 8 * g + 4 * kh) * 4);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int prow = row_base + 2 * j + lr;
+        const int pl = prow * TW + lcx;                                   // pixel inside the tile
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = i * 32 + 8 * g + 4 * kh;                   // channel inside the block
+                v4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = (T)(acc[i][j][4 * g + e] + addv[i][g][e]);
+                *reinterpret_cast<v4 *>(stg + pl * 256 + ((((cl >> 3) ^ (pl & 15)) << 4) | ((cl & 7) * 2))) = ov;
+            }
+    }
+    __syncthreads();
+    life(4);
+
+    // ---- epilogue 2: residual (row-coalesced 16-B reads) + full-row stores + per-channel statistics ------
+    constexpr int RPE = NT / 16;                         // pixel rows handled per pass (16)
+    constexpr int NPASS = BM / RPE;
+    const int c16 = tid & 15, prw = tid >> 4;            // 16-byte chunk (8 channels), pixel row slot
+    v8 rres[NPASS];
+    if (a.resid) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int pl = prw + RPE * i;
+            const size_t m = (size_t)(b * H + y0 + (pl >> 4)) * Wd + x0 + (pl & 15);
+            rres[i] = *reinterpret_cast<const v8 *>((const T *)a.resid + m * a.Cout + n0 + c16 * 8);
+        }
+    }
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const int pl = prw + RPE * i;
+        v8 v = *reinterpret_cast<const v8 *>(stg + pl * 256 + ((c16 ^ (pl & 15)) << 4));
+        if (a.resid) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rres[i][e]);
+        }
+        const size_t m = (size_t)(b * H + y0 + (pl >> 4)) * Wd + x0 + (pl & 15);
+        *reinterpret_cast<v8 *>((T *)a.out + m * a.Cout + n0 + c16 * 8) = v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = (float)v[e];
+            s1[e] += f;
+            s2[e] = fmaf(f, f, s2[e]);
+        }
+    }
+    if (a.stats) {
+        // the four row slots of a wave (lanes l, l^16, l^32, l^48) in a fixed order, then the four waves through LDS
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s1[e] += __shfl_xor(s1[e], 16);
+            s2[e] += __shfl_xor(s2[e], 16);
+            s1[e] += __shfl_xor(s1[e], 32);
+            s2[e] += __shfl_xor(s2[e], 32);
+        }
+        float *red = reinterpret_cast<float *>(smem + BM * 256);           // [4 waves][128][2]
+        if (l < 16) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[((w * 128) + c16 * 8 + e) * 2 + 0] = s1[e];
+                red[((w * 128) + c16 * 8 + e) * 2 + 1] = s2[e];
+            }
+        }
+        __syncthreads();
+        const float t = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+        a.stats[((size_t)(b * tps + tin) * a.Cout + n0) * 2 + tid] = t;
+    }
+    life(5);
+}
+
+template <int TH> constexpr int t32_smem_bytes() {
+    constexpr int NPIECE = (TH + 2) * 18 * 4, NROUND = (NPIECE + 255) / 256;
+    constexpr int NREMW = (NPIECE - (NROUND - 1) * 256 + 63) / 64;
+    constexpr int PATCH_BYTES = (NROUND - 1) * 4096 + NREMW * 1024;
+    constexpr int main_bytes = 2 * PATCH_BYTES + 4 * 8192 + T32_SS_BYTES + T32_MAX_CHUNKS * 16 + 512 + 1024;
+    constexpr int epi_bytes = TH * 16 * 256 + 4 * 128 * 2 * 4;
+    return main_bytes > epi_bytes ? main_bytes : epi_bytes;
+}
+
+template <typename T, int TH, int ABL>
+int launch_t32_t(const FusedArgs &a, hipStream_t st) {
+    constexpr int smem = t32_smem_bytes<TH>();
+    static_assert(smem <= 80 * 1024, "LDS budget: two workgroups per CU");
+    static bool attr = false;
+    if (!attr) {
+        BNDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_t32<T, TH, ABL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr = true;
+        if (getenv("BNDM_T32_DEBUG")) {
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&conv_t32<T, TH, ABL>),
+                                                               256, smem);
+            fprintf(stderr, "[bndm] conv_t32<TH=%d>: %d B of LDS, %d resident workgroups per CU (occupancy query)\n", TH,
+                    smem, nb);
+        }
+    }
+    const int tiles_x = a.W / 16, tiles_y = a.H / TH, tps = tiles_x * tiles_y, ntn = a.Cout / 128;
+    int nsteps = 0;
+    for (int i = 0; i < a.nseg; ++i) nsteps += a.seg[i].taps * (a.seg[i].C / 32);
+    dim3 grid(a.B * tps * ntn);
+    // half a workgroup's MFMA time (16 MFMAs of 32 cycles per K-step and wave; twice that while two workgroups share)
+    static const int stagger_pct = getenv("BNDM_T32_STAGGER") ? atoi(getenv("BNDM_T32_STAGGER")) : 50;
+    const int stagger = grid.x > 256 ? (int)((long long)nsteps * 1024 * (TH / 8) / 2 * stagger_pct / 100) : 0;
+    unsigned *dbg = nullptr;
+    if constexpr ((ABL & 64) != 0) {
+        static unsigned *buf = nullptr;
+        if (!buf) BNDM_CHECK_HIP(hipMalloc(&buf, (4 * 9 * 6 + 32) * sizeof(unsigned)));
+        dbg = buf;
+    }
+    hipLaunchKernelGGL((conv_t32<T, TH, ABL>), grid, dim3(256), smem, st, a, tiles_x, tps, ntn, nsteps, stagger, dbg);
+    if constexpr ((ABL & 64) != 0) {
+        // profiling aid: dump the marks of 8-chunk launches (the K = 2304 layers) as text
+        int n9 = 0;
+        for (int i = 0; i < a.nseg; ++i) n9 += a.seg[i].taps == 9 ? a.seg[i].C / 32 : 0;
+        if (n9 == 8 && getenv("BNDM_T32_TRACE")) {
+            unsigned h[4 * 9 * 6 + 32];
+            BNDM_CHECK_HIP(hipStreamSynchronize(st));
+            BNDM_CHECK_HIP(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+            FILE *f = fopen(getenv("BNDM_T32_TRACE"), "w");
+            if (f) {
+                for (int w = 0; w < 4; ++w)
+                    for (int t = 0; t < 9; ++t) {
+                        fprintf(f, "w%d t%d", w, t);
+                        for (int k = 0; k < 5; ++k) fprintf(f, " %u", h[(w * 9 + t) * 6 + k] - h[0]);
+                        fprintf(f, "\n");
+                    }
+                for (int blk = 0; blk < 2; ++blk) {
+                    fprintf(f, "life blk%d", blk ? 700 : 0);
+                    for (int k = 0; k < 6; ++k) fprintf(f, " %u", h[216 + 16 * blk + k] - h[216]);
+                    fprintf(f, "\n");
+                }
+                fclose(f);
+            }
+        }
+    }
+    return launch_status("conv_t32");
+}
+
+}  // namespace
+
+// true when conv_t32 can run this segment list: 3x3 segments first, 1x1 segments after them
+bool conv_t32_supports(const FusedArgs &a) {
+    bool seen1 = false;
+    int nchunks = 0;
+    for (int i = 0; i < a.nseg; ++i) {
+        if (a.seg[i].C % 32 || a.seg[i].C > 2047) return false;
+        if (a.seg[i].taps == 1) seen1 = true;
+        else if (seen1) return false;
+        else if ((a.seg[i].ss_off >= 0) != (a.seg[0].ss_off >= 0)) return false;   // all 3x3 segments normalised, or none
+        nchunks += a.seg[i].C / 32;
+    }
+    // 32-bit buffer offsets: every source tensor must stay below 2 GiB
+    for (int i = 0; i < a.nseg; ++i) {
+        const long long px = a.seg[i].up ? (long long)(a.H / 2) * (a.W / 2) : (long long)a.H * a.W;
+        if ((long long)a.B * px * a.seg[i].C * 2 >= (1LL << 31)) return false;
+    }
+    if (a.ss && 2 * a.ssC * 4 > T32_SS_BYTES) return false;
+    return a.nseg >= 1 && a.seg[0].taps == 9 && nchunks <= T32_MAX_CHUNKS && a.Cout % 128 == 0 && a.W % 16 == 0;
+}
+
+int conv_t32_tiles_per_sample(int TH, int H, int W) { return (H / TH) * (W / 16); }
+
+// Host-side weight packing for conv_t32: out[n-tile][K-step][row r of 128][physical slot j of 4][8 elements], where
+// K-steps run over the 3x3 segments' 32-channel chunks x 9 taps, then over the 1x1 segments' chunks, and slot j of row
+// r holds channels 8 (j ^ ((r >> 2) & 3)) .. +7 of the step.  `w_of(seg, co, c, tap)` returns the fp32 weight.
+std::vector<float> pack_weights_t32(const FusedSeg *seg, int nseg, int Cout,
+                                    const std::function<float(int, int, int, int)> &w_of) {
+    int nsteps = 0;
+    for (int i = 0; i < nseg; ++i) nsteps += seg[i].taps * (seg[i].C / 32);
+    const int ntn = (Cout + 127) / 128;
+    std::vector<float> out((size_t)ntn * nsteps * 128 * 32, 0.f);
+    int step = 0;
+    for (int pass = 0; pass < 2; ++pass)                 // 3x3 segments first
+        for (int i = 0; i < nseg; ++i) {
+            if ((seg[i].taps == 9) != (pass == 0)) continue;
+            for (int ci = 0; ci < seg[i].C / 32; ++ci)
+                for (int t = 0; t < seg[i].taps; ++t, ++step)
+                    for (int nt = 0; nt < ntn; ++nt)
+                        for (int r = 0; r < 128; ++r) {
+                            const int co = nt * 128 + r;
+                            if (co >= Cout) continue;
+                            for (int j = 0; j < 4; ++j) {
+                                const int s = j ^ ((r >> 2) & 3);
+                                float *dst = &out[(((size_t)nt * nsteps + step) * 128 + r) * 32 + j * 8];
+                                for (int e = 0; e < 8; ++e) dst[e] = w_of(i, co, ci * 32 + s * 8 + e, t);
+                            }
+                        }
+        }
+    return out;
+}
+
+int launch_conv_t32(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
+    static const int abl = getenv("BNDM_ABLATE") ? atoi(getenv("BNDM_ABLATE")) : 0;
+    if (dtype == BNDM_DTYPE_F16) {
+        if (abl && TH == 16) {
+            switch (abl) {
+                case 1: return launch_t32_t<_Float16, 16, 1>(a, st);
+                case 2: return launch_t32_t<_Float16, 16, 2>(a, st);
+                case 4: return launch_t32_t<_Float16, 16, 4>(a, st);
+                case 8: return launch_t32_t<_Float16, 16, 8>(a, st);
+                case 16: return launch_t32_t<_Float16, 16, 16>(a, st);
+                case 14: return launch_t32_t<_Float16, 16, 14>(a, st);
+                case 15: return launch_t32_t<_Float16, 16, 15>(a, st);
+                case 64: return launch_t32_t<_Float16, 16, 64>(a, st);
+                default: break;
+            }
+        }
+        return TH == 16 ? launch_t32_t<_Float16, 16, 0>(a, st) : launch_t32_t<_Float16, 8, 0>(a, st);
+    }
+    return TH == 16 ? launch_t32_t<__bf16, 16, 0>(a, st) : launch_t32_t<__bf16, 8, 0>(a, st);
+}
+
+}  // namespace bndm

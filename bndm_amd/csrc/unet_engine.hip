@@ -474,11 +474,15 @@ struct Builder {
     bool can_fuse(int H, int W, int Cout) const {
         return use_fused && H >= 16 && W >= 16 && H >= fused_min && H <= fused_max && Cout % 128 == 0;
     }
-    void conv_fused(const std::vector<FIn> &ins, bool normed, int ssC, bool silu, const void *Wp, int Ktot,
+    void conv_fused(const std::vector<FIn> &ins, const std::vector<WSeg> &ws, bool normed, int ssC, bool silu,
                     const float *bias, int temb_off, const Act *resid, const Act &out, bool want_stats,
                     const std::string &label) {
         materialize();
         bndm_unet *hh = h;
+        static const bool use_tap9 = getenv("BNDM_CONV") && !strcmp(getenv("BNDM_CONV"), "tap9");
+        const void *Wp = nullptr;
+        int Ktot = 0;
+        for (const WSeg &w : ws) Ktot += w.taps * w.C;
         FusedArgs a{};
         a.nseg = (int)ins.size();
         std::vector<int> slots;
@@ -493,26 +497,43 @@ struct Builder {
         }
         a.ssC = ssC;
         a.silu = silu ? 1 : 0;
-        a.Wgt = Wp;
-        a.Ktot = Ktot;
         a.bias = bias;
         a.temb_off = temb_off >= 0 ? temb_off : 0;
         a.H = out.H;
         a.W = out.W;
         a.Cout = out.C;
         a.zeros = h->zeros;
-        // 256-pixel tiles unless that leaves CUs idle at this handle's batch size (small per-GPU batches)
+        // 256-pixel tiles unless that leaves workgroup slots idle at this handle's batch size
         int TH = out.H >= 32 ? 16 : 8;
-        if (TH == 16 && (long long)h->cfg.max_batch * (out.H / 16) * (out.W / 16) * (out.C / 128) < 192) TH = 8;
-        {
+        const long long tiles16 = (long long)h->cfg.max_batch * (out.H / 16) * (out.W / 16) * (out.C / 128);
+        static const int th16_min = getenv("BNDM_TH16_MIN") ? atoi(getenv("BNDM_TH16_MIN")) : 192;
+        if (TH == 16 && tiles16 < (use_tap9 ? 192 : th16_min)) TH = 8;
+        if (use_tap9) {
+            if ((rc = pack_conv_weight(h, ws, out.C, 128, &Wp, &Ktot))) return;
             const std::vector<int> tab = build_fused_steps(a.seg, a.nseg, TH, conv_fused_threads(TH));
             void *dtab;
             if ((rc = upload(h, tab.data(), tab.size() * sizeof(int), &dtab))) return;
             a.steps = dtab;
+        } else {
+            a.Ktot = Ktot;
+            a.B = h->cfg.max_batch;
+            a.ss = normed ? (const float *)h->zeros : nullptr;
+            if (!conv_t32_supports(a)) {
+                set_error("conv_t32 cannot run %s (segment list / ssC=%d / tensor size)", label.c_str(), ssC);
+                rc = BNDM_E_ARG;
+                return;
+            }
+            const std::vector<float> wp = pack_weights_t32(a.seg, a.nseg, out.C, [&](int si, int co, int c, int t) {
+                const WSeg &w = ws[si];
+                return (*w.w)[((size_t)co * w.cin_total + w.c_begin + c) * w.taps + t];
+            });
+            if ((rc = upload_16(h, wp, &Wp))) return;
         }
+        a.Wgt = Wp;
+        a.Ktot = Ktot;
         const int rs = resid ? resid->slot : -1, so = out.slot;
         int pst = -1;
-        if (want_stats) pst = new_stats(out, conv_fused_tiles_per_sample(TH, out.H, out.W)).pslot;
+        if (want_stats) pst = new_stats(out, conv_t32_tiles_per_sample(TH, out.H, out.W)).pslot;
         else stats_of.erase(out.slot);
         cur_name = S("cnvF %-44s K=%-5d N=%-4d %dx%d", label.c_str(), Ktot, out.C, out.H, out.W);
         double abytes = 2.0 * out.C * out.H * out.W * (resid ? 2 : 1);
@@ -529,10 +550,10 @@ struct Builder {
             c.resid = rs >= 0 ? hh->P(rs) : nullptr;
             c.out = hh->P(so);
             c.stats = pst >= 0 ? (float *)hh->P(pst) : nullptr;
-            return launch_conv_fused(hh->dtype(), TH, c, r.st);
+            return use_tap9 ? launch_conv_fused(hh->dtype(), TH, c, r.st) : launch_conv_t32(hh->dtype(), TH, c, r.st);
         });
         h->ops[op_index].dominant = TH == 16;
-        h->ops[op_index].kernel = S("conv_tap9<TH=%d>", TH);
+        h->ops[op_index].kernel = S(use_tap9 ? "conv_tap9<TH=%d>" : "conv_t32<TH=%d>", TH);
         h->ops[op_index].bytes_per_sample = abytes;
         h->ops[op_index].bytes_fixed = wbytes;
     }
@@ -692,31 +713,29 @@ struct Builder {
             const std::vector<float> &b = h->hp(name + ".time_emb_proj.bias");
             tp_w.insert(tp_w.end(), w.begin(), w.end());
             tp_b.insert(tp_b.end(), b.begin(), b.end());
+            // conv1's bias rides in the projection's bias: the conv epilogue then adds ONE row (temb) instead of two
+            const std::vector<float> &cb = h->hp(name + ".conv1.bias");
+            for (int c = 0; c < Cout; ++c) tp_b[temb_cursor + c] += cb[c];
             temb_cursor += Cout;
         }
+        const float *bias1 = has_temb ? nullptr : bias_of(name + ".conv1");
         if (can_fuse(H, W, Cout)) {
             // conv1: GN(norm1)+SiLU applied to cat(x1, x2) inside the conv prologue
             gn_table(x1, x2, name + ".norm1");
             if (rc) return x1;
-            const void *W1;
-            int K1;
             std::vector<WSeg> w1{WSeg{&h->hp(name + ".conv1.weight"), Cin, 0, C1, 9}};
             std::vector<FIn> in1{FIn{x1, 9, 0, 0}};
             if (x2) {
                 w1.push_back(WSeg{&h->hp(name + ".conv1.weight"), Cin, C1, C2, 9});
                 in1.push_back(FIn{*x2, 9, 0, C1});
             }
-            if ((rc = pack_conv_weight(h, w1, Cout, 128, &W1, &K1))) return x1;
             Act h1 = scratch(h->s_h1, Cout, H, W);
-            conv_fused(in1, true, Cin, true, W1, K1, bias_of(name + ".conv1"), temb_off, nullptr, h1, true,
-                       name + ".conv1");
+            conv_fused(in1, w1, true, Cin, true, bias1, temb_off, nullptr, h1, true, name + ".conv1");
             if (rc) return x1;
             // conv2 (+ 1x1 conv_shortcut on the raw inputs, or identity residual)
             gn_table(h1, nullptr, name + ".norm2");
             if (rc) return x1;
             Act out = new_act(Cout, H, W);
-            const void *W2;
-            int K2;
             std::vector<WSeg> w2{WSeg{&h->hp(name + ".conv2.weight"), Cout, 0, Cout, 9}};
             std::vector<FIn> in2{FIn{h1, 9, 0, 0}};
             const float *b2;
@@ -733,8 +752,7 @@ struct Builder {
                 b2 = bias_of(name + ".conv2");
             }
             if (rc) return x1;
-            if ((rc = pack_conv_weight(h, w2, Cout, 128, &W2, &K2))) return x1;
-            conv_fused(in2, true, Cout, true, W2, K2, b2, -1, Cin == Cout ? &x1 : nullptr, out, true,
+            conv_fused(in2, w2, true, Cout, true, b2, -1, Cin == Cout ? &x1 : nullptr, out, true,
                        name + (Cin != Cout ? ".conv2+sc" : ".conv2"));
             return out;
         }
@@ -746,7 +764,7 @@ struct Builder {
         rc = pack_conv_weight(h, {WSeg{&h->hp(name + ".conv1.weight"), Cin, 0, Cin, 9}}, Cout, 128, &W1, &K1);
         if (rc) return x1;
         Act h1 = scratch(h->s_h1, Cout, H, W);
-        conv({SegIn{y1, 9, 0}}, W1, K1, bias_of(name + ".conv1"), temb_off, nullptr, h1, 1, name + ".conv1", true);
+        conv({SegIn{y1, 9, 0}}, W1, K1, bias1, temb_off, nullptr, h1, 1, name + ".conv1", true);
         Act y2 = scratch(h->s_y2, Cout, H, W);
         group_norm(h1, nullptr, name + ".norm2", true, y2);
         if (rc) return x1;
@@ -886,15 +904,16 @@ struct Builder {
     }
 
     Act resample(const Act &x, const std::string &name, bool down) {
+        Act out = down ? new_act(x.C, x.H / 2, x.W / 2) : new_act(x.C, x.H * 2, x.W * 2);
+        if (!down && can_fuse(out.H, out.W, out.C)) {
+            conv_fused({FIn{x, 9, 1, -1}}, {WSeg{&h->hp(name + ".weight"), x.C, 0, x.C, 9}}, false, 0, false, bias_of(name),
+                       -1, nullptr, out, true, name);
+            return out;
+        }
         const void *Wp;
         int K;
         rc = pack_conv_weight(h, {WSeg{&h->hp(name + ".weight"), x.C, 0, x.C, 9}}, x.C, 128, &Wp, &K);
         if (rc) return x;
-        Act out = down ? new_act(x.C, x.H / 2, x.W / 2) : new_act(x.C, x.H * 2, x.W * 2);
-        if (!down && can_fuse(out.H, out.W, out.C)) {
-            conv_fused({FIn{x, 9, 1, -1}}, false, 0, false, Wp, K, bias_of(name), -1, nullptr, out, true, name);
-            return out;
-        }
         conv({SegIn{x, 9, down ? 0 : 1}}, Wp, K, bias_of(name), -1, nullptr, out, down ? 2 : 1, name);
         return out;
     }

@@ -3,6 +3,7 @@
 // embeddings and accumulators are fp32.
 #pragma once
 #include "common.hpp"
+#include <functional>
 #include <vector>
 
 namespace bndm {
@@ -129,6 +130,13 @@ int conv_fused_threads(int TH);
 // tap-unrolled variant of the same kernel (unet_tap9.hip); used whenever it supports the segment list
 bool conv_tap9_supports(const FusedArgs &a);
 int launch_conv_tap9(int dtype, int TH, const FusedArgs &a, hipStream_t st);
+// conv_t32 (unet_conv32.hip): 256-thread workgroups, two per CU, 32-channel K-steps, tile-contiguous weights
+bool conv_t32_supports(const FusedArgs &a);
+int launch_conv_t32(int dtype, int TH, const FusedArgs &a, hipStream_t st);
+int conv_t32_tiles_per_sample(int TH, int H, int W);
+// w_of(segment, out channel, channel within the segment, tap) -> fp32 weight; result is [n-tile][K-step][128][32]
+std::vector<float> pack_weights_t32(const FusedSeg *seg, int nseg, int Cout,
+                                    const std::function<float(int, int, int, int)> &w_of);
 // the same kernel with specialised waves (8 MFMA waves + 4 patch-DMA / normalisation waves; unet_tap9s.hip)
 int launch_conv_tap9s(int dtype, int TH, const FusedArgs &a, hipStream_t st);
 

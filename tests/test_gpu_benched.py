@@ -1,7 +1,7 @@
 """Oracle parity of the kernel set the benchmark actually runs ("What's missing" 1).
 
-The engine picks tile variants from the handle's batch size (``max_batch``): small batches run ``conv_tap9<TH=8>``
-on the 64x64 layers, the benchmarked B=64 runs ``conv_tap9<TH=16>`` on every 64x64 and 32x32 layer.  These tests run the
+The engine picks tile variants from the handle's batch size (``max_batch``): small batches run ``conv_t32<TH=8>``
+on the 64x64 layers, the benchmarked B=64 runs ``conv_t32<TH=16>`` on every 64x64 and 32x32 layer.  These tests run the
 full network at the per-GPU batch sizes of BASELINE.json's configurations -- c2 res64 3->6 B=64 (f16 and bf16),
 c4 res128 3->6 B=32, c5 latent 4->8 B=8 -- against oracle/unet_oracle.py with the same seeded weights, and ASSERT from
 the engine's op list (bndm_unet_op_info) that the benched kernel variant is on the path, so a future heuristic change
@@ -45,8 +45,8 @@ def test_res64_B64_runs_the_benched_kernels_and_matches_oracle(dtype, tol):
     m, U, cfg, sd = _pair(64, 3, 6, dtype)
     B = 64
     kinds = _kernels_by_resolution(m, B, 64)
-    assert ("conv_tap9<TH=16>", "64x64") in kinds and ("conv_tap9<TH=16>", "32x32") in kinds, sorted(kinds)
-    assert ("conv_tap9<TH=8>", "64x64") not in kinds
+    assert ("conv_t32<TH=16>", "64x64") in kinds and ("conv_t32<TH=16>", "32x32") in kinds, sorted(kinds)
+    assert ("conv_t32<TH=8>", "64x64") not in kinds
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, 3, 64, 64, generator=g)
     t = torch.linspace(0.004, 1.0, B)
@@ -64,7 +64,7 @@ def test_res128_B32_matches_oracle():
     m, U, cfg, sd = _pair(128, 3, 6)
     B = 32
     kinds = _kernels_by_resolution(m, B, 128)
-    assert ("conv_tap9<TH=16>", "128x128") in kinds and ("conv_tap9<TH=8>", "128x128") not in kinds, sorted(kinds)
+    assert ("conv_t32<TH=16>", "128x128") in kinds and ("conv_t32<TH=8>", "128x128") not in kinds, sorted(kinds)
     x = torch.randn(B, 3, 128, 128, generator=torch.Generator().manual_seed(1))
     t = torch.linspace(0.01, 1.0, B)
     ref = U.forward(sd, cfg, x, t)
@@ -79,7 +79,7 @@ def test_latent_B8_matches_oracle():
     m, U, cfg, sd = _pair(64, 4, 8, latent=True)
     B = 8
     kinds = {k for k, _ in _kernels_by_resolution(m, B, 64)}
-    assert any(k.startswith("conv_tap9") for k in kinds)
+    assert any(k.startswith("conv_t32") for k in kinds)
     x = torch.randn(B, 4, 64, 64, generator=torch.Generator().manual_seed(2))
     t = torch.linspace(0.1, 1.0, B)
     ref = U.forward(sd, cfg, x, t)
