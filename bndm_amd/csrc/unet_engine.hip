@@ -8,6 +8,7 @@
 // norm/bias tables and activation workspaces sized for max_batch.  forward() is a fixed list of
 // kernel launches built once in finalize(); nothing is allocated or synchronised per call.
 #include "unet_kernels.hpp"
+#include "unet_f32.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -115,6 +116,7 @@ struct Op {
 struct bndm_unet {
     bndm_unet_config cfg{};
     int kind = 0;                      // 0: UNet2DModel, 1: AutoencoderKL decoder (cfg.resolution = latent H = W)
+    F32Model *f32 = nullptr;           // BNDM_DTYPE_F32: the whole forward runs in csrc/unet_f32.hip
     int temb_dim = 0;
     std::vector<ParamSpec> params;
     std::unordered_map<std::string, int> pindex;
@@ -314,7 +316,7 @@ struct WSeg {
 
 // Wp[co][koff + tap*C + c] = w[co][c_begin + c][tap]; rows padded with zeros to a multiple of `row_pad`
 int pack_conv_weight(bndm_unet *h, const std::vector<WSeg> &segs, int Cout, int row_pad, const void **out,
-                     int *Ktot_out) {
+                     int *Ktot_out, bool tiled = true) {
     int Ktot = 0;
     for (const WSeg &s : segs) Ktot += s.taps * s.C;
     const int rows = ceil_div(Cout, row_pad) * row_pad;
@@ -329,6 +331,20 @@ int pack_conv_weight(bndm_unet *h, const std::vector<WSeg> &segs, int Cout, int 
         koff += s.taps * s.C;
     }
     *Ktot_out = Ktot;
+    if (tiled && row_pad == 128 && Ktot % 64 == 0) {
+        // tile-contiguous, pre-swizzled layout of the 128-row igemm tiles (ConvArgs::wtiled)
+        std::vector<float> wt(wp.size());
+        const int ks = Ktot / 64;
+        for (int nt = 0; nt < rows / 128; ++nt)
+            for (int s = 0; s < ks; ++s)
+                for (int r = 0; r < 128; ++r)
+                    for (int j = 0; j < 8; ++j) {
+                        const float *src = &wp[(size_t)(nt * 128 + r) * Ktot + s * 64 + (j ^ ((r >> 1) & 7)) * 8];
+                        float *dst = &wt[(((size_t)nt * ks + s) * 128 + r) * 64 + j * 8];
+                        for (int e = 0; e < 8; ++e) dst[e] = src[e];
+                    }
+        return upload_16(h, wt, out);
+    }
     return upload_16(h, wp, out);
 }
 
@@ -509,7 +525,7 @@ struct Builder {
         static const int th16_min = getenv("BNDM_TH16_MIN") ? atoi(getenv("BNDM_TH16_MIN")) : 192;
         if (TH == 16 && tiles16 < (use_tap9 ? 192 : th16_min)) TH = 8;
         if (use_tap9) {
-            if ((rc = pack_conv_weight(h, ws, out.C, 128, &Wp, &Ktot))) return;
+            if ((rc = pack_conv_weight(h, ws, out.C, 128, &Wp, &Ktot, false))) return;
             const std::vector<int> tab = build_fused_steps(a.seg, a.nseg, TH, conv_fused_threads(TH));
             void *dtab;
             if ((rc = upload(h, tab.data(), tab.size() * sizeof(int), &dtab))) return;
@@ -623,6 +639,13 @@ struct Builder {
         a.Cout = out.C;
         a.Ktot = Ktot;
         a.zeros = h->zeros;
+        {
+            double act = 0;
+            for (const SegIn &f : ins) act += (double)h->cfg.max_batch * f.a.H * f.a.W * f.a.C;
+            static const int wm = getenv("BNDM_WMAJOR") ? atoi(getenv("BNDM_WMAJOR")) : 1;
+            a.wmajor = wm && (double)out.C * Ktot > act ? 1 : 0;
+            a.wtiled = 1;                                // every caller packs with pack_conv_weight(..., 128, ...)
+        }
         {
             bool any_up = false;
             for (int i = 0; i < a.nseg; ++i) any_up = any_up || a.seg[i].up;
@@ -1212,6 +1235,7 @@ struct Builder {
             a.Ktot = K;
             a.splitk = 1;
             a.zeros = h->zeros;
+            a.wtiled = 1;
             auto mlp_fn = h->temb_table_fn;
             h->temb_table_fn = [=](int n, const float *t_dev, void *act, float *table, hipStream_t st) {
                 int e = mlp_fn(n, t_dev, act, table, st);
@@ -1236,6 +1260,7 @@ struct Builder {
 };
 
 int run_forward(bndm_unet *h, RunCtx &r) {
+    if (h->f32) return f32_model_forward(h->f32, r.sample, r.extra, r.timesteps, r.out, r.B, r.st);
     for (size_t i = 0; i < h->ops.size(); ++i) {
         if (r.prof) BNDM_CHECK_HIP(hipEventRecord((*r.ev)[2 * i], r.st));
         int e = h->ops[i].run(r);
@@ -1298,8 +1323,10 @@ extern "C" int bndm_unet_create(bndm_unet **out, const bndm_unet_config *cfg) {
     BNDM_REQUIRE(out && cfg, "bndm_unet_create: NULL argument");
     BNDM_REQUIRE(cfg->num_levels >= 2 && cfg->num_levels <= BNDM_MAX_LEVELS, "bndm_unet_create: num_levels %d",
                  cfg->num_levels);
-    BNDM_REQUIRE(cfg->dtype == BNDM_DTYPE_F16 || cfg->dtype == BNDM_DTYPE_BF16, "bndm_unet_create: dtype %d",
-                 cfg->dtype);
+    BNDM_REQUIRE(cfg->dtype == BNDM_DTYPE_F16 || cfg->dtype == BNDM_DTYPE_BF16 || cfg->dtype == BNDM_DTYPE_F32,
+                 "bndm_unet_create: dtype %d", cfg->dtype);
+    BNDM_REQUIRE(cfg->dtype != BNDM_DTYPE_F32 || cfg->max_batch <= 8,
+                 "bndm_unet_create: the fp32-compute mode is a verification mode, max_batch %d > 8", cfg->max_batch);
     BNDM_REQUIRE(cfg->resolution >= 16 && (cfg->resolution & (cfg->resolution - 1)) == 0,
                  "bndm_unet_create: resolution %d must be a power of two >= 16", cfg->resolution);
     BNDM_REQUIRE((cfg->resolution >> (cfg->num_levels - 1)) >= 1, "bndm_unet_create: too many levels for resolution");
@@ -1393,6 +1420,7 @@ extern "C" void bndm_unet_destroy(bndm_unet *h) {
     if (h->t_pinned) (void)hipHostFree(h->t_pinned);
     if (h->t_uploaded) (void)hipEventDestroy(h->t_uploaded);
     for (void *p : h->retired) (void)hipFree(p);
+    if (h->f32) f32_model_destroy(h->f32);
     for (Buf &b : h->bufs)
         if (b.ptr) (void)hipFree(b.ptr);
     delete h;
@@ -1443,6 +1471,19 @@ extern "C" int bndm_unet_finalize(bndm_unet *h) {
             set_error("bndm_unet_finalize: missing key '%s'", h->params[i].name.c_str());
             return BNDM_E_STATE;
         }
+    if (h->cfg.dtype == BNDM_DTYPE_F32) {
+        std::vector<std::string> names;
+        for (const ParamSpec &ps : h->params) names.push_back(ps.name);
+        int rc = f32_model_create(h->cfg, names, h->host, &h->f32);
+        if (rc) return rc;
+        h->s_t = h->new_slot((size_t)h->cfg.max_batch * 4);
+        h->s_d = h->new_slot((size_t)h->cfg.max_batch * h->cfg.out_channels * h->cfg.resolution * h->cfg.resolution * 4);
+        for (Buf &bf : h->bufs) BNDM_CHECK_HIP(hipMalloc(&bf.ptr, bf.bytes ? bf.bytes : 16));
+        for (auto &v : h->host) std::vector<float>().swap(v);
+        BNDM_CHECK_HIP(hipDeviceSynchronize());
+        h->finalized = true;
+        return 0;
+    }
     Builder b{h};
     if (const char *e = getenv("BNDM_NO_FUSED")) b.use_fused = !(e[0] == '1');
     if (const char *e = getenv("BNDM_NO_GN_SMALL")) b.use_gn_small = !(e[0] == '1');
@@ -1485,10 +1526,11 @@ extern "C" int bndm_unet_sample_iadb(bndm_unet *h, float *x, const float *extra_
     float *tbuf = (float *)h->P(h->s_t), *dbuf = (float *)h->P(h->s_d);
     const size_t img = (size_t)B * C * R * R;
     int snap = 0;
-    if (nb_step > 0 && (rc = prepare_temb_table(h, nb_step, t_in, st))) return rc;
+    if (nb_step > 0 && !h->f32 && (rc = prepare_temb_table(h, nb_step, t_in, st))) return rc;
     for (int s = 0; s < nb_step; ++s) {
         RunCtx r{B, st, x, extra_in, tbuf, dbuf};
-        r.tp_row = h->tp_table + (size_t)s * h->ntemb;
+        if (h->f32) hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(64), 0, st, tbuf, t_in[s], B);
+        else r.tp_row = h->tp_table + (size_t)s * h->ntemb;
         if ((rc = run_forward(h, r))) return rc;
         if ((rc = bndm_iadb_step(x, dbuf, da[s], dg[s], B, C, Cout, R * R, stream))) return rc;
         if (snap_mask && snapshots && snap_mask[s]) {
@@ -1512,12 +1554,13 @@ extern "C" int bndm_unet_sample_ddim(bndm_unet *h, float *x, int B, int nb_step,
     if (nb_step > 0) {
         std::vector<float> ts(nb_step);
         for (int s = 0; s < nb_step; ++s) ts[s] = coef[5 * s];
-        if ((rc = prepare_temb_table(h, nb_step, ts.data(), st))) return rc;     // copied to pinned staging there
+        if (!h->f32 && (rc = prepare_temb_table(h, nb_step, ts.data(), st))) return rc;   // copied to pinned staging there
     }
     for (int s = 0; s < nb_step; ++s) {
         const float *c = coef + 5 * s;
         RunCtx r{B, st, x, nullptr, tbuf, dbuf};
-        r.tp_row = h->tp_table + (size_t)s * h->ntemb;
+        if (h->f32) hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(64), 0, st, tbuf, c[0], B);
+        else r.tp_row = h->tp_table + (size_t)s * h->ntemb;
         if ((rc = run_forward(h, r))) return rc;
         if ((rc = bndm_ddim_step(x, dbuf, c[1], c[2], c[3], c[4], clip, n, stream))) return rc;
     }
@@ -1529,6 +1572,7 @@ extern "C" int bndm_unet_profile(bndm_unet *h, const float *sample, const float 
     int rc = check_ready(h, B, "bndm_unet_profile");
     if (rc) return rc;
     BNDM_REQUIRE(sample && timesteps && out && prof && iters >= 1, "bndm_unet_profile: bad argument");
+    BNDM_REQUIRE(!h->f32, "bndm_unet_profile: the fp32-compute mode has no per-kernel profile");
     hipStream_t st = (hipStream_t)stream;
     const size_t nops = h->ops.size();
     std::vector<hipEvent_t> ev(2 * nops);

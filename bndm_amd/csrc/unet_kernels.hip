@@ -88,7 +88,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
         const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
         tix = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int mt = tix / ntn, nt = tix - mt * ntn;
+    const int mt = a.wmajor ? tix % ntm : tix / ntn, nt = a.wmajor ? tix / ntm : tix - mt * ntn;
     const int m0 = mt * BM, n0 = nt * BN;
     const int M = a.B << (logW + logH);
     const int H = a.H, Wd = a.W;
@@ -114,9 +114,11 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
         pb[i] = (m < M) ? (m >> (logW + logH)) : -1;
     }
     const char *wsrc[NWP];
+    const size_t wstep = a.wtiled ? (size_t)BN * 128 : 128;          // bytes between consecutive K-steps
 #pragma unroll
     for (int i = 0; i < NWP; ++i)
-        wsrc[i] = (const char *)a.Wgt + ((size_t)(n0 + prow + RPI * i) * a.Ktot + lchunk * 8) * 2;
+        wsrc[i] = a.wtiled ? (const char *)a.Wgt + ((size_t)nt * ksteps * BN + prow + RPI * i) * 128 + (tid & 7) * 16
+                           : (const char *)a.Wgt + ((size_t)(n0 + prow + RPI * i) * a.Ktot + lchunk * 8) * 2;
     // FAST path: centre-tap source pixel and tap-validity mask of every piece
     int pbase[NXP], vmask[NXP];
     if (FAST) {
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
         }
 #pragma unroll
         for (int i = 0; i < NWP; ++i)
-            glds16(wsrc[i] + (size_t)kc * 128, base + X_BYTES + i * (RPI * 128) + w * 1024);
+            glds16(wsrc[i] + (size_t)kc * wstep, base + X_BYTES + i * (RPI * 128) + w * 1024);
     };
 
     auto stage = [&](int buf, const KIter &k, int ks) {
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
         }
 #pragma unroll
         for (int i = 0; i < NWP; ++i)
-            glds16(wsrc[i] + (size_t)min(ks, ksteps - 1) * 128, base + X_BYTES + i * (RPI * 128) + w * 1024);
+            glds16(wsrc[i] + (size_t)min(ks, ksteps - 1) * wstep, base + X_BYTES + i * (RPI * 128) + w * 1024);
     };
 
     f32x16 acc[TN][TM];

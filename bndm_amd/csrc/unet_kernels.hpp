@@ -38,6 +38,10 @@ struct ConvArgs {
     const void *steps;   // device copy of build_conv_steps(...) or nullptr (generic addressing)
     float *part;         // EPI_SPLITK_FUSED: fp32 slabs [splitk][M][Cout]
     unsigned *counters;  // EPI_SPLITK_FUSED: one arrival counter per output tile (zero before first use)
+    int wtiled;          // 1: Wgt is tile-contiguous and pre-swizzled, [Cout/128][K/64][128 rows][8 slots][8]: slot j of
+                         // row r holds k-group j ^ ((r >> 1) & 7) of the step -- one linear 16 KiB read per K-step
+    int wmajor;          // 1: consecutive tiles (same XCD, dispatched together) share the WEIGHT panel (same n-tile,
+                         // neighbouring m-tiles) -- for layers whose weights outweigh their activations (<= 8x8)
 };
 
 // EPI_SPLITK_FUSED: every K-slice block writes its fp32 slab; the last block to arrive at a tile sums the

@@ -25,7 +25,7 @@ from torch import nn
 
 from . import _lib
 
-DTYPE_F16, DTYPE_BF16 = 0, 1
+DTYPE_F16, DTYPE_BF16, DTYPE_F32 = 0, 1, 2
 
 
 @dataclass
@@ -208,7 +208,8 @@ class UNet2DModel(nn.Module):
             cfg.down_attn[i] = int(c["down_block_types"][i] == "AttnDownBlock2D")
             cfg.up_attn[i] = int(c["up_block_types"][i] == "AttnUpBlock2D")
         cfg.layers_per_block = c["layers_per_block"]
-        cfg.dtype = {"f16": DTYPE_F16, "fp16": DTYPE_F16, "bf16": DTYPE_BF16}[self.compute_dtype]
+        cfg.dtype = {"f16": DTYPE_F16, "fp16": DTYPE_F16, "bf16": DTYPE_BF16, "f32": DTYPE_F32,
+                     "fp32": DTYPE_F32}[self.compute_dtype]
         max_batch = max(B, 1)
         cfg.max_batch = max_batch
         h = C.c_void_p()

@@ -106,6 +106,8 @@ typedef struct bndm_unet bndm_unet;
 #define BNDM_MAX_LEVELS 8
 #define BNDM_DTYPE_F16  0
 #define BNDM_DTYPE_BF16 1
+#define BNDM_DTYPE_F32  2  /* fp32-compute verification mode: fp32 NCHW, plain FMA kernels, max_batch <= 8.
+                            * The reference's own arithmetic (iadb_bn.py:304-344 samples in fp32, no autocast). */
 
 typedef struct bndm_unet_config {
     int in_channels;
