@@ -328,10 +328,12 @@ __global__ __launch_bounds__(256, 2) void conv_t32(const FusedArgs a, const int 
     Chunk cur = load_chunk(0);
     Chunk nxt = cur;
     {
-        const __amdgpu_buffer_rsrc_t srs =
-            uniform_rsrc(a.ss ? a.ss + (size_t)b * 2 * a.ssC : (const float *)a.zeros, a.ss ? 2 * a.ssC * 4 : 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_ptr_t)(smem + OFF_SS + w * 1024), 16, (unsigned)(tid * 16), 0,
-                                                 0, 0);
+        if (!a.gn_p1) {
+            const __amdgpu_buffer_rsrc_t srs =
+                uniform_rsrc(a.ss ? a.ss + (size_t)b * 2 * a.ssC : (const float *)a.zeros, a.ss ? 2 * a.ssC * 4 : 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_ptr_t)(smem + OFF_SS + w * 1024), 16, (unsigned)(tid * 16),
+                                                     0, 0, 0);
+        }
         // the tile's additive row (the launcher passes bias OR the time-embedding row, which has the bias folded in):
         // 32 pieces by the first lanes of wave 0 (its other lanes and the other waves read zeros into the dead slot,
         // which starts right behind the row)
@@ -354,7 +356,62 @@ __global__ __launch_bounds__(256, 2) void conv_t32(const FusedArgs a, const int 
         w_issue(1, 1);
         w_issue(2, 2);
         w_issue(3, 3);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NWP) : "memory");      // table + own patch pieces landed
+        if (a.gn_p1) {
+            // GroupNorm(32) statistics of cat(x1, x2) for this sample from the producers' per-tile partial sums (fixed slab
+            // order, fp64 group combine: the arithmetic of gn_finalize2), while the DMAs above are in flight.  Scratch: the
+            // second patch buffer, idle until the main loop.
+            float *cs = reinterpret_cast<float *>(smem + PATCH_BYTES), *css = cs + 512;
+            const int C = a.ssC, C1 = a.gn_C1;
+            float gam[2], bet[2];                        // C <= 512: at most two channels per thread; loaded up front
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c = tid + k * NT;
+                gam[k] = c < C ? a.gn_gamma[c] : 0.f;
+                bet[k] = c < C ? a.gn_beta[c] : 0.f;
+            }
+            for (int c = tid; c < C; c += NT) {
+                const bool first = c < C1;
+                const float *p = first ? a.gn_p1 : a.gn_p2;
+                const int ns = first ? a.gn_ns1 : a.gn_ns2, Cs = first ? C1 : C - C1, cc = first ? c : c - C1;
+                float2 v[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    v[k] = k < ns ? *reinterpret_cast<const float2 *>(p + ((size_t)(b * ns + k) * Cs + cc) * 2) : float2{0.f, 0.f};
+                float s = 0.f, q2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    s += v[k].x;
+                    q2 += v[k].y;
+                }
+                cs[c] = s;
+                css[c] = q2;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int Cg = C >> 5;
+            float *ssW = reinterpret_cast<float *>(smem + OFF_SS);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const int c = tid + k2 * NT;
+                if (c >= C) break;
+                const int g0 = (c / Cg) * Cg;
+                double s = 0, q2 = 0;
+                for (int k = 0; k < Cg; ++k) {
+                    s += cs[g0 + k];
+                    q2 += css[g0 + k];
+                }
+                const double n = (double)Cg * a.gn_HW;
+                const double mean = s / n;
+                double var = q2 / n - mean * mean;
+                var = var > 0 ? var : 0;
+                const float rstd = (float)(1.0 / sqrt(var + (double)a.gn_eps));
+                const float sc = rstd * gam[k2];
+                ssW[c] = sc;
+                ssW[C + c] = bet[k2] - (float)mean * sc;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * NWP) : "memory");   // table + own patch pieces landed
         __builtin_amdgcn_s_barrier();                         // ... in every wave (the table is shared)
         asm volatile("" ::: "memory");
         if (!(ABL & 8) && cur.ssbase >= 0) {

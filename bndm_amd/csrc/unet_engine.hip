@@ -105,10 +105,10 @@ struct Op {
     double flops_per_sample;   // algorithmic 2*MAC per batch element (convs only)
     std::function<int(RunCtx &)> run;
     std::string name;
-    bool dominant = false;          // conv_fused, 256-pixel tiles
+    bool dominant = false;          // conv_t32 with 256-pixel tiles
     double bytes_per_sample = 0;    // algorithmic HBM bytes per batch element (activations)
     double bytes_fixed = 0;         // weights
-    std::string kernel;             // kernel family (and tile variant) this op launches, e.g. "conv_tap9<TH=16>"
+    std::string kernel;             // kernel family (and tile variant) this op launches, e.g. "conv_t32<TH=16>"
 };
 
 }  // namespace
@@ -316,7 +316,7 @@ struct WSeg {
 
 // Wp[co][koff + tap*C + c] = w[co][c_begin + c][tap]; rows padded with zeros to a multiple of `row_pad`
 int pack_conv_weight(bndm_unet *h, const std::vector<WSeg> &segs, int Cout, int row_pad, const void **out,
-                     int *Ktot_out, bool tiled = true) {
+                     int *Ktot_out) {
     int Ktot = 0;
     for (const WSeg &s : segs) Ktot += s.taps * s.C;
     const int rows = ceil_div(Cout, row_pad) * row_pad;
@@ -331,7 +331,7 @@ int pack_conv_weight(bndm_unet *h, const std::vector<WSeg> &segs, int Cout, int 
         koff += s.taps * s.C;
     }
     *Ktot_out = Ktot;
-    if (tiled && row_pad == 128 && Ktot % 64 == 0) {
+    if (row_pad == 128 && Ktot % 64 == 0) {
         // tile-contiguous, pre-swizzled layout of the 128-row igemm tiles (ConvArgs::wtiled)
         std::vector<float> wt(wp.size());
         const int ks = Ktot / 64;
@@ -381,7 +381,7 @@ struct Builder {
         h->ops.push_back(Op{cls, flops, std::move(fn), cur_name});
         // kernel family from the op label's four-letter tag; conv_fused() overwrites it with the tile variant
         static const std::pair<const char *, const char *> fam[] = {
-            {"cnvF", "conv_tap9"}, {"conv", "conv_igemm"}, {"gnst", "gn_stats"}, {"gnfn", "gn_finalize2"},
+            {"cnvF", "conv_t32"}, {"conv", "conv_igemm"}, {"gnst", "gn_stats"}, {"gnfn", "gn_finalize2"},
             {"gnsm", "gn_small"}, {"gnap", "gn_apply"}, {"rdce", "splitk_reduce"}, {"attn", "attention"},
             {"temb", "temb_mlp"}, {"post", "pointwise_f32"}, {"deco", "conv_in"}};
         Op &op = h->ops.back();
@@ -413,16 +413,35 @@ struct Builder {
         return sr;
     }
 
-    // scale/shift table of GroupNorm(32)(cat(x1, x2)) -> scratch slot s_ss
-    void gn_table(const Act &x1, const Act *x2, const std::string &pname) {
+    // GroupNorm(32)(cat(x1, x2)) for a fused consumer: either the consumer finalises the statistics itself from the
+    // producers' per-tile partial sums (<= 16 slabs each: conv_t32's prologue), or a gn_finalize2 launch writes the
+    // scale / shift table to scratch slot s_ss first
+    struct GnSpec {
+        StatRef a1, a2;
+        int C1 = 0, C2 = 0, HW = 0;
+        const float *gamma = nullptr, *beta = nullptr;
+        bool inkernel = false;
+    };
+    bool use_gn_inkernel = true;
+    GnSpec gn_table(const Act &x1, const Act *x2, const std::string &pname) {
         materialize();
         bndm_unet *hh = h;
+        GnSpec g;
         const int C1 = x1.C, C2 = x2 ? x2->C : 0, C = C1 + C2, HW = x1.H * x1.W;
         const StatRef a1 = ensure_stats(x1);
         const StatRef a2 = x2 ? ensure_stats(*x2) : StatRef{};
         const float *gamma, *beta;
-        if ((rc = upload_f32(h, h->hp(pname + ".weight"), &gamma))) return;
-        if ((rc = upload_f32(h, h->hp(pname + ".bias"), &beta))) return;
+        if ((rc = upload_f32(h, h->hp(pname + ".weight"), &gamma))) return g;
+        if ((rc = upload_f32(h, h->hp(pname + ".bias"), &beta))) return g;
+        g.a1 = a1;
+        g.a2 = a2;
+        g.C1 = C1;
+        g.C2 = C2;
+        g.HW = HW;
+        g.gamma = gamma;
+        g.beta = beta;
+        g.inkernel = use_gn_inkernel && a1.nslab <= 16 && (!x2 || a2.nslab <= 16) && C <= 512;
+        if (g.inkernel) return g;
         h->grow(h->s_ss, (size_t)h->cfg.max_batch * 2 * C * 4);
         cur_name = S("gnfn %-44s C=%-4d %dx%d", pname.c_str(), C, x1.H, x1.W);
         const float eps_ = gn_eps;
@@ -431,6 +450,7 @@ struct Builder {
                                        a2.pslot >= 0 ? (const float *)hh->P(a2.pslot) : nullptr, a2.nslab, C2, r.B, HW,
                                        GROUPS, eps_, gamma, beta, (float *)hh->P(hh->s_ss), r.st);
         });
+        return g;
     }
 
     // GroupNorm(32) of cat(x1, x2) followed by optional SiLU, materialised -> out (unfused path)
@@ -472,7 +492,12 @@ struct Builder {
             return;
         }
         materialize();
-        gn_table(x1, x2, pname);
+        {
+            const bool keep = use_gn_inkernel;
+            use_gn_inkernel = false;                     // gn_apply reads the table from s_ss
+            gn_table(x1, x2, pname);
+            use_gn_inkernel = keep;
+        }
         if (rc) return;
         const int s1 = x1.slot, s2 = x2 ? x2->slot : -1, so = out.slot;
         cur_name = S("gnap %-44s C=%-4d %dx%d", pname.c_str(), C1 + C2, x1.H, x1.W);
@@ -482,7 +507,7 @@ struct Builder {
         });
     }
 
-    // fused 3x3 conv launch (csrc/unet_fused.hip)
+    // fused 3x3 conv launch (csrc/unet_conv32.hip)
     struct FIn {
         Act a;
         int taps, up, ss_off;
@@ -490,12 +515,15 @@ struct Builder {
     bool can_fuse(int H, int W, int Cout) const {
         return use_fused && H >= 16 && W >= 16 && H >= fused_min && H <= fused_max && Cout % 128 == 0;
     }
-    void conv_fused(const std::vector<FIn> &ins, const std::vector<WSeg> &ws, bool normed, int ssC, bool silu,
+    void conv_fused(const std::vector<FIn> &ins, const std::vector<WSeg> &ws, const GnSpec *gs, bool silu,
                     const float *bias, int temb_off, const Act *resid, const Act &out, bool want_stats,
                     const std::string &label) {
+        const bool normed = gs != nullptr;
+        const int ssC = gs ? gs->C1 + gs->C2 : 0;
+        const GnSpec g = gs ? *gs : GnSpec{};
+        const float eps_ = gn_eps;
         materialize();
         bndm_unet *hh = h;
-        static const bool use_tap9 = getenv("BNDM_CONV") && !strcmp(getenv("BNDM_CONV"), "tap9");
         const void *Wp = nullptr;
         int Ktot = 0;
         for (const WSeg &w : ws) Ktot += w.taps * w.C;
@@ -523,14 +551,8 @@ struct Builder {
         int TH = out.H >= 32 ? 16 : 8;
         const long long tiles16 = (long long)h->cfg.max_batch * (out.H / 16) * (out.W / 16) * (out.C / 128);
         static const int th16_min = getenv("BNDM_TH16_MIN") ? atoi(getenv("BNDM_TH16_MIN")) : 192;
-        if (TH == 16 && tiles16 < (use_tap9 ? 192 : th16_min)) TH = 8;
-        if (use_tap9) {
-            if ((rc = pack_conv_weight(h, ws, out.C, 128, &Wp, &Ktot, false))) return;
-            const std::vector<int> tab = build_fused_steps(a.seg, a.nseg, TH, conv_fused_threads(TH));
-            void *dtab;
-            if ((rc = upload(h, tab.data(), tab.size() * sizeof(int), &dtab))) return;
-            a.steps = dtab;
-        } else {
+        if (TH == 16 && tiles16 < th16_min) TH = 8;
+        {
             a.Ktot = Ktot;
             a.B = h->cfg.max_batch;
             a.ss = normed ? (const float *)h->zeros : nullptr;
@@ -561,15 +583,26 @@ struct Builder {
             for (int i = 0; i < c.nseg; ++i) c.seg[i].src = hh->P(slots[i]);
             c.B = r.B;
             c.ss = normed ? (const float *)hh->P(hh->s_ss) : nullptr;
+            if (normed && g.inkernel) {
+                c.gn_p1 = (const float *)hh->P(g.a1.pslot);
+                c.gn_p2 = g.a2.pslot >= 0 ? (const float *)hh->P(g.a2.pslot) : nullptr;
+                c.gn_ns1 = g.a1.nslab;
+                c.gn_ns2 = g.a2.nslab;
+                c.gn_C1 = g.C1;
+                c.gn_HW = g.HW;
+                c.gn_gamma = g.gamma;
+                c.gn_beta = g.beta;
+                c.gn_eps = eps_;
+            }
             c.temb = temb_off >= 0 ? (r.tp_row ? r.tp_row : (const float *)hh->P(hh->s_tp)) : nullptr;
             c.temb_bstride = r.tp_row ? 0 : hh->ntemb;
             c.resid = rs >= 0 ? hh->P(rs) : nullptr;
             c.out = hh->P(so);
             c.stats = pst >= 0 ? (float *)hh->P(pst) : nullptr;
-            return use_tap9 ? launch_conv_fused(hh->dtype(), TH, c, r.st) : launch_conv_t32(hh->dtype(), TH, c, r.st);
+            return launch_conv_t32(hh->dtype(), TH, c, r.st);
         });
         h->ops[op_index].dominant = TH == 16;
-        h->ops[op_index].kernel = S(use_tap9 ? "conv_tap9<TH=%d>" : "conv_t32<TH=%d>", TH);
+        h->ops[op_index].kernel = S("conv_t32<TH=%d>", TH);
         h->ops[op_index].bytes_per_sample = abytes;
         h->ops[op_index].bytes_fixed = wbytes;
     }
@@ -744,7 +777,7 @@ struct Builder {
         const float *bias1 = has_temb ? nullptr : bias_of(name + ".conv1");
         if (can_fuse(H, W, Cout)) {
             // conv1: GN(norm1)+SiLU applied to cat(x1, x2) inside the conv prologue
-            gn_table(x1, x2, name + ".norm1");
+            const GnSpec g1 = gn_table(x1, x2, name + ".norm1");
             if (rc) return x1;
             std::vector<WSeg> w1{WSeg{&h->hp(name + ".conv1.weight"), Cin, 0, C1, 9}};
             std::vector<FIn> in1{FIn{x1, 9, 0, 0}};
@@ -753,10 +786,10 @@ struct Builder {
                 in1.push_back(FIn{*x2, 9, 0, C1});
             }
             Act h1 = scratch(h->s_h1, Cout, H, W);
-            conv_fused(in1, w1, true, Cin, true, bias1, temb_off, nullptr, h1, true, name + ".conv1");
+            conv_fused(in1, w1, &g1, true, bias1, temb_off, nullptr, h1, true, name + ".conv1");
             if (rc) return x1;
             // conv2 (+ 1x1 conv_shortcut on the raw inputs, or identity residual)
-            gn_table(h1, nullptr, name + ".norm2");
+            const GnSpec g2 = gn_table(h1, nullptr, name + ".norm2");
             if (rc) return x1;
             Act out = new_act(Cout, H, W);
             std::vector<WSeg> w2{WSeg{&h->hp(name + ".conv2.weight"), Cout, 0, Cout, 9}};
@@ -775,7 +808,7 @@ struct Builder {
                 b2 = bias_of(name + ".conv2");
             }
             if (rc) return x1;
-            conv_fused(in2, w2, true, Cout, true, b2, -1, Cin == Cout ? &x1 : nullptr, out, true,
+            conv_fused(in2, w2, &g2, true, b2, -1, Cin == Cout ? &x1 : nullptr, out, true,
                        name + (Cin != Cout ? ".conv2+sc" : ".conv2"));
             return out;
         }
@@ -929,7 +962,7 @@ struct Builder {
     Act resample(const Act &x, const std::string &name, bool down) {
         Act out = down ? new_act(x.C, x.H / 2, x.W / 2) : new_act(x.C, x.H * 2, x.W * 2);
         if (!down && can_fuse(out.H, out.W, out.C)) {
-            conv_fused({FIn{x, 9, 1, -1}}, {WSeg{&h->hp(name + ".weight"), x.C, 0, x.C, 9}}, false, 0, false, bias_of(name),
+            conv_fused({FIn{x, 9, 1, -1}}, {WSeg{&h->hp(name + ".weight"), x.C, 0, x.C, 9}}, nullptr, false, bias_of(name),
                        -1, nullptr, out, true, name);
             return out;
         }
@@ -1485,9 +1518,10 @@ extern "C" int bndm_unet_finalize(bndm_unet *h) {
         return 0;
     }
     Builder b{h};
-    if (const char *e = getenv("BNDM_NO_FUSED")) b.use_fused = !(e[0] == '1');
+    if (const char *e = getenv("BNDM_NO_FUSED")) b.use_fused = !(e[0] == '1');     // debugging: igemm + gn_apply everywhere
     if (const char *e = getenv("BNDM_NO_GN_SMALL")) b.use_gn_small = !(e[0] == '1');
     if (const char *e = getenv("BNDM_NO_DEFER")) b.use_defer = !(e[0] == '1');
+    if (const char *e = getenv("BNDM_NO_GN_INKERNEL")) b.use_gn_inkernel = !(e[0] == '1');
     if (const char *e = getenv("BNDM_FUSED_MIN")) b.fused_min = atoi(e);
     if (const char *e = getenv("BNDM_FUSED_MAX")) b.fused_max = atoi(e);
     int rc = h->kind == 1 ? b.build_vae() : b.build();

@@ -88,13 +88,13 @@ int gn_num_slabs(int HW);
 }  // namespace bndm
 
 // ------------------------------------------------------------------------------------------------
-// Fused 3x3 convolution (stride 1) for the high-resolution, FLOP-dominant layers.
-//   prologue : GroupNorm scale/shift (+SiLU) applied while the (TH+2)x18 input halo patch of a
-//              64-channel chunk is staged into LDS -- once per element, not once per tap;
-//   main loop: 9 taps read MFMA fragments from the same LDS patch at shifted pixel offsets, weight
-//              tiles streamed by global_load_lds (double-buffered);
-//   epilogue : bias + time embedding + residual, tile staged through LDS for full-row stores, and
-//              per-(sample, channel) sum / sum-of-squares of the stored values for the next GroupNorm.
+// Fused 3x3 convolution (stride 1) for the high-resolution, FLOP-dominant layers: conv_t32 (unet_conv32.hip).
+//   input side : GroupNorm scale/shift (+SiLU) applied in place to the (TH+2)x18 input halo patch of a 32-channel
+//                chunk after it has been brought into LDS -- once per element, not once per tap;
+//   main loop  : 9 taps read MFMA fragments from the same LDS patch at shifted pixel offsets, weight tiles streamed
+//                by LDS-DMA through a 4-slot ring;
+//   epilogue   : bias / time embedding + residual, tile staged through LDS for full-row stores, and
+//                per-(sample, tile, channel) sum / sum-of-squares of the stored values for the next GroupNorm.
 // ------------------------------------------------------------------------------------------------
 namespace bndm {
 
@@ -112,7 +112,7 @@ struct FusedArgs {
     const float *ss;     // [B][2][ssC] scale / shift, nullptr when no segment is normalised
     int ssC;
     int silu;
-    const void *Wgt;     // same packing as ConvArgs: [Cout_pad][Ktot], k = segment -> tap -> channel
+    const void *Wgt;     // pack_weights_t32: [Cout/128][K-step][128 rows][32 k], pre-swizzled
     int Ktot;
     const float *bias;
     const float *temb;
@@ -121,19 +121,16 @@ struct FusedArgs {
     void *out;           // NHWC 16-bit
     float *stats;        // [B][tiles_per_sample][Cout][2] or nullptr
     int B, H, W, Cout;
-    const void *zeros;   // >= 16 bytes of zeros (source of padding pieces)
-    const void *steps;   // device copy of build_fused_steps(seg, nseg, TH)
+    const void *zeros;   // >= 16 bytes of zeros
+    // In-kernel GroupNorm finalisation (gn_p1 != nullptr; `ss` is then ignored): every workgroup turns the per-tile
+    // partial sums of its sample into the scale / shift table itself, in its prologue -- no gn_finalize2 launch.
+    // gn_p1 / gn_p2: [B][gn_ns1 / gn_ns2][gn_C1 / ssC - gn_C1][2] (sum, sum of squares); at most 16 slabs each.
+    const float *gn_p1, *gn_p2, *gn_gamma, *gn_beta;
+    int gn_ns1, gn_ns2, gn_C1, gn_HW;
+    float gn_eps;
 };
 
 // TH = 16 (256-pixel tiles) or 8 (128-pixel tiles); W must be a multiple of 16, H of TH
-int launch_conv_fused(int dtype, int TH, const FusedArgs &a, hipStream_t st);
-int conv_fused_tiles_per_sample(int TH, int H, int W);
-// per-step schedule table of conv_fused (host side; upload and pass as FusedArgs::steps)
-std::vector<int> build_fused_steps(const FusedSeg *seg, int nseg, int TH, int nthreads);
-int conv_fused_threads(int TH);
-// tap-unrolled variant of the same kernel (unet_tap9.hip); used whenever it supports the segment list
-bool conv_tap9_supports(const FusedArgs &a);
-int launch_conv_tap9(int dtype, int TH, const FusedArgs &a, hipStream_t st);
 // conv_t32 (unet_conv32.hip): 256-thread workgroups, two per CU, 32-channel K-steps, tile-contiguous weights
 bool conv_t32_supports(const FusedArgs &a);
 int launch_conv_t32(int dtype, int TH, const FusedArgs &a, hipStream_t st);
@@ -141,9 +138,6 @@ int conv_t32_tiles_per_sample(int TH, int H, int W);
 // w_of(segment, out channel, channel within the segment, tap) -> fp32 weight; result is [n-tile][K-step][128][32]
 std::vector<float> pack_weights_t32(const FusedSeg *seg, int nseg, int Cout,
                                     const std::function<float(int, int, int, int)> &w_of);
-// the same kernel with specialised waves (8 MFMA waves + 4 patch-DMA / normalisation waves; unet_tap9s.hip)
-int launch_conv_tap9s(int dtype, int TH, const FusedArgs &a, hipStream_t st);
-
 // one-launch GroupNorm(+SiLU) for small per-sample tensors (statistics + apply, one block per sample)
 // x1 given as split-K partial sums: element = round16(sum_z part[z] + bias + temb + resid); the rounded value is also
 // stored to raw_out (the tensor splitk_reduce would have produced, bit-identical)

@@ -136,7 +136,7 @@ int  bndm_unet_load_param(bndm_unet *h, const char *name, const float *host_data
 int  bndm_unet_finalize(bndm_unet *h);
 
 /* The launch list of one forward, fixed at finalize (it depends on max_batch: tile variants are chosen for the
- * handle's batch size).  kernel: family + tile variant ("conv_tap9<TH=16>", "conv_igemm", "gn_small", ...); label: the
+ * handle's batch size).  kernel: family + tile variant ("conv_t32<TH=16>", "conv_igemm", "gn_small", ...); label: the
  * layer it computes (diffusers module path).  Lets a test assert which kernels a configuration runs; no reference
  * counterpart (the reference's launch list is whatever eager PyTorch dispatches at iadb_bn.py:319). */
 int  bndm_unet_num_ops(const bndm_unet *h);

@@ -185,12 +185,13 @@ def test_conditional_superres_loop_matches_oracle():
     assert _rel(got.cpu(), ref) <= 2e-3
 
 
-@pytest.mark.parametrize("env", [{"BNDM_TAP9_SPEC": "1"}, {"BNDM_TAP9_NW": "4"}, {"BNDM_FUSED_V": "6"},
-                                 {"BNDM_NO_DEFER": "1", "BNDM_NO_GN_SMALL": "1"}])
+@pytest.mark.parametrize("env", [{"BNDM_NO_FUSED": "1"}, {"BNDM_NO_DEFER": "1", "BNDM_NO_GN_SMALL": "1"},
+                                 {"BNDM_TH16_MIN": "100000"}])
 def test_alternative_kernel_paths_match_oracle(env):
-    """The opt-in variants of the fused conv (wave-specialised conv_tap9s, 4-wave conv_tap9, the previous
-    conv_fused) and the un-fused GroupNorm / split-K reduce path are selected by process-wide environment
-    switches: run one forward of a 3-level network in a child process per setting, same bar as the default."""
+    """The one fallback of the fused convolution (implicit-GEMM conv + materialised GroupNorm everywhere,
+    BNDM_NO_FUSED), the un-fused small GroupNorm / split-K reduce path, and conv_t32 forced onto its 128-pixel tiles are
+    selected by process-wide environment switches: run one forward of a 3-level network in a child process per
+    setting, same bar as the default."""
     import os, subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent('''
