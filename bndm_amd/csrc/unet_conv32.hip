@@ -514,6 +514,7 @@ __global__ __launch_bounds__(256, 2) void conv_t32(const FusedArgs a, const int 
             constexpr int r = s >= 3 && s <= 7 && s - 3 < NFULL ? s - 3 : -1;
             // the phase is its own scheduling region: the group pattern below must only see this phase's instructions
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((ABL & 512) != 0) __builtin_amdgcn_s_setprio(1);
             mma_refill(kcur, tnext, knext);
             xf_math(sc, pc);
             if constexpr (!(ABL & 1) && !(ABL & 4) && !(ABL & 32)) {
@@ -527,6 +528,7 @@ __global__ __launch_bounds__(256, 2) void conv_t32(const FusedArgs a, const int 
                     __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                         // VALU in the shadow
                 }
             }
+            if constexpr ((ABL & 512) != 0) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         };
         auto mark = [&](int t, int k) {
@@ -870,6 +872,7 @@ int launch_conv_t32(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
                 case 14: return launch_t32_t<_Float16, 16, 14>(a, st);
                 case 15: return launch_t32_t<_Float16, 16, 15>(a, st);
                 case 64: return launch_t32_t<_Float16, 16, 64>(a, st);
+                case 512: return launch_t32_t<_Float16, 16, 512>(a, st);
                 default: break;
             }
         }

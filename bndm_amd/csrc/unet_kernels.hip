@@ -119,14 +119,17 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
     for (int i = 0; i < NWP; ++i)
         wsrc[i] = a.wtiled ? (const char *)a.Wgt + ((size_t)nt * ksteps * BN + prow + RPI * i) * 128 + (tid & 7) * 16
                            : (const char *)a.Wgt + ((size_t)(n0 + prow + RPI * i) * a.Ktot + lchunk * 8) * 2;
-    // FAST path: centre-tap source pixel and tap-validity mask of every piece
+    // FAST path: centre-tap source pixel and tap-validity mask of every piece.  The per-step part of the address (tap
+    // shift, channel chunk) is a scalar from the host-built step table; the source is read through a buffer descriptor
+    // whose base sits one row + one pixel BEFORE the tensor, so that every tap shift is a non-negative scalar offset, and
+    // padding taps get an out-of-range offset (the descriptor returns zeros): one multiply-add and one select per piece.
     int pbase[NXP], vmask[NXP];
+    const int Hs = H * a.stride, Ws = Wd * a.stride;
     if (FAST) {
-        const int Hs = H * a.stride, Ws = Wd * a.stride;
 #pragma unroll
         for (int i = 0; i < NXP; ++i) {
             const int cy = py[i] * a.stride, cx = px[i] * a.stride;
-            pbase[i] = (pb[i] * Hs + cy) * Ws + cx;
+            pbase[i] = pb[i] >= 0 ? (pb[i] * Hs + cy) * Ws + cx : 0;
             int vm = 0;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -155,14 +158,14 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
         dsc = stab[min(ks + 1, ksteps - 1)];
         const ConvSeg sg = seg_of(d.x & 0xff);
         const int tap = (d.x >> 8) & 0xf;
-        const char *sbase = (const char *)sg.src;
-        const int coff = d.z + lchunk * 8;
+        const int C2 = sg.C * 2, lead = (Ws + 1) * C2;                   // bytes of one row + one pixel
+        const __amdgpu_buffer_rsrc_t rs = uniform_rsrc((const char *)sg.src - lead, a.B * Hs * Ws * C2 + lead);
+        const int soff = __builtin_amdgcn_readfirstlane(d.w);            // (tap shift + row + pixel) * C2 + chunk * 128
 #pragma unroll
         for (int i = 0; i < NXP; ++i) {
             const bool ok = (vmask[i] >> tap) & 1;
-            const long off = ((long)(pbase[i] + d.y) * sg.C + coff) * 2;
-            const char *src = ok ? sbase + off : (const char *)a.zeros;
-            glds16(src, base + i * (RPI * 128) + w * 1024);
+            const unsigned voff = ok ? (unsigned)(pbase[i] * C2 + lchunk * 16) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(base + i * (RPI * 128) + w * 1024), 16, voff, soff, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < NWP; ++i)
@@ -809,7 +812,8 @@ int launch_conv_cfg(const ConvArgs &a, hipStream_t st) {
     // the table-driven path pays ~100 VALU of per-piece set-up: only worth it with enough K-steps per block
     int ksteps = 0;
     for (int i = 0; i < a.nseg; ++i) ksteps += a.seg[i].taps * (a.seg[i].C / 64);
-    bool fast = a.steps != nullptr && ksteps / (a.splitk > 1 ? a.splitk : 1) >= 12;
+    static const int fast_min = getenv("BNDM_IGEMM_FAST_MIN") ? atoi(getenv("BNDM_IGEMM_FAST_MIN")) : 4;
+    bool fast = a.steps != nullptr && ksteps / (a.splitk > 1 ? a.splitk : 1) >= fast_min;
     for (int i = 0; i < a.nseg; ++i) fast = fast && !a.seg[i].up;
     return fast ? launch_conv_cfg2<T, WM, WN, TM, TN, EPI, STAGES, true>(a, st)
                 : launch_conv_cfg2<T, WM, WN, TM, TN, EPI, STAGES, false>(a, st);
@@ -993,7 +997,7 @@ std::vector<int> build_conv_steps(const ConvSeg *seg, int nseg, int W_out, int s
                 out.push_back(i | (tap << 8));
                 out.push_back(dy * Ws + dx);
                 out.push_back(c * 64);
-                out.push_back(0);
+                out.push_back(((dy + 1) * Ws + (dx + 1)) * seg[i].C * 2 + c * 128);     // scalar byte offset of the step
             }
     return out;
 }
