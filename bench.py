@@ -318,21 +318,28 @@ def main():
     if rank == 0 and wl["L"] is not None:
         L = wl["L"]
 
-        def time_noise(nb, reps=20):
+        def time_noise(nb, reps=200):
+            """us per bndm_bluenoise call (both kernels), called through the C ABI with caller-owned buffers -- the
+            Python wrapper's allocations would dominate a 15-us transform."""
             zz = torch.randn(nb, 3, 64, 64, device=dev)
-            aa = torch.ones(nb, device=dev)
-            tt = torch.full((nb,), N, device=dev)
-            for _ in range(3):
-                get_noise_v2(dev, zz, L, aa, tt, noise_type="GBN", train_or_test="test", inplace=True,
-                             l_is_triangular=True)
+            outs = [torch.empty_like(zz) for _ in range(3)]
+            wsb = lib.bndm_bluenoise_workspace_bytes(nb, 3, 64)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            p = lambda t: C.c_void_p(t.data_ptr())
+            stream = _lib.current_stream_ptr()
+
+            def call():
+                return lib.bndm_bluenoise(p(L), 0, p(zz), 0, C.c_void_p(0), p(outs[0]), p(outs[1]), p(outs[2]), nb, 0, nb, 3,
+                                          64, 1, p(ws), wsb, stream)
+            for _ in range(5):
+                _lib.check(call(), "bndm_bluenoise")
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
-                get_noise_v2(dev, zz, L, aa, tt, noise_type="GBN", train_or_test="test", inplace=True,
-                             l_is_triangular=True)
+                call()
             e1.record()
             torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / reps * 1e3            # us per call (all kernels of the call)
+            return e0.elapsed_time(e1) / reps * 1e3
         TRI = 4096 * 4097 // 2
         us_small, us_batch = time_noise(2), time_noise(64)
         stages = {

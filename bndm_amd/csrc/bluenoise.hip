@@ -12,7 +12,7 @@
 //      (double-buffered), so every byte of L is fetched from HBM in full 256-B row pieces and
 //      ds_read_b128 fragment reads are bank-conflict free.  Partial sums go to per-segment slabs
 //      (deterministic: no atomics).
-//   2. bluenoise_finish: sums the <=4 slabs in fixed order and writes noise / noise_bn / noise_wn
+//   2. bluenoise_finish: sums the <=4 (<=32 behind bluenoise_small) slabs in fixed order and writes noise / noise_bn / noise_wn
 //      in the reference's output layouts (32-px crop, 128-px slot placement and the scrambled
 //      white-noise view), with the per-sample lerp evaluated in the reference's operation order.
 //
@@ -161,6 +161,169 @@ __global__ __launch_bounds__(256) void bluenoise_gemm(const float *__restrict__ 
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// HBM regime (at most 32 z-columns, i.e. B <= 10 RGB images of 64 px): the transform is bound by the ONE read of L's
+// lower triangle (33.5 MB), and bluenoise_gemm's 160 work units of 64 rows x 1024 k leave 96 CUs idle and spend their
+// time in MFMAs on padding columns.  bluenoise_small cuts the triangle into 528 units of 128 rows x 128 k (1024 for a
+// dense L), four resident per CU: a workgroup of 4 waves stages 32-k slices of its 128 L rows (128-B row pieces,
+// 16-B LDS-DMA, XOR-swizzled) and of the z columns through a double buffer; wave w multiplies rows 32w..32w+31 with
+// the exact-f32 MFMA (32x32x2 for 17..32 columns, 16x16x4 for <= 16 columns: half the matrix-pipe time), skipping the
+// slices of the diagonal unit that lie wholly above its rows.  Partial sums go to per-segment slabs (no atomics);
+// bluenoise_finish sums the i/128 + 1 slabs of row i in segment order.
+constexpr int SM_BM = 128, SM_BK = 32, SM_KSEG = 128;
+constexpr int SM_NSEG = NPIX / SM_KSEG;          // 32
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <bool W16>
+__global__ __launch_bounds__(256, 4) void bluenoise_small(const float *__restrict__ L, ZSrc zs, float *__restrict__ part,
+                                                          int ncols, int f_begin, int dense) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * (SM_BM * SM_BK * 4 + 32 * SM_BK * 4)];
+    constexpr int L_BYTES = SM_BM * SM_BK * 4;       // 16 KiB: 128 rows x 128 B
+    constexpr int Z_BYTES = 32 * SM_BK * 4;          //  4 KiB:  32 cols x 128 B
+    constexpr int STAGE = L_BYTES + Z_BYTES;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l = tid & 63;
+
+    // ---- work units: (128-row panel P, 128-k segment S), S <= P unless dense.  A lower-triangular L has 496
+    // off-diagonal units and 32 diagonal ones (which read 10/16 of a unit: rows above a 32-k slice hold only zeros and
+    // are not fetched); the diagonal units are paired, so that the grid is 512 workgroups = two per CU, every one with
+    // 1 .. 1.25 units of HBM traffic -- the per-CU LDS-DMA rate (~25 GB/s), not the chip's bandwidth, sets the time.
+    int Pu[2], Su[2], nunit = 1;
+    {
+        const int u = blockIdx.x;
+        if (dense) {
+            Pu[0] = 31 - (u >> 5);
+            Su[0] = u & 31;
+        } else if (u < 496) {                      // off-diagonal units, longest panels first: panel P has P of them
+            int rem = u, P = 31;
+            while (rem >= P) {
+                rem -= P;
+                --P;
+            }
+            Pu[0] = P;
+            Su[0] = rem;
+        } else {                                   // diagonal units (P, P), paired bottom with top
+            Pu[0] = Su[0] = 31 - (u - 496);
+            Pu[1] = Su[1] = u - 496;
+            nunit = 2;
+        }
+        if (nunit == 1) Pu[1] = Su[1] = 0;
+    }
+    for (int un = 0; un < nunit; ++un) {
+    const int P = __builtin_amdgcn_readfirstlane(Pu[un]), S = __builtin_amdgcn_readfirstlane(Su[un]);
+    const bool diag = !dense && S == P;
+    const int i0 = P * SM_BM, kbeg = S * SM_KSEG;
+
+    // ---- staging: piece q of a 4-KiB block instruction = row q >> 3, physical chunk q & 7 holds logical chunk
+    // (q & 7) ^ ((row >> 1) & 7)
+    const int prow = tid >> 3, pchunk = tid & 7;
+    const float *lsrc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = r * 32 + prow;
+        lsrc[r] = L + (size_t)(i0 + row) * NPIX + kbeg + 4 * (pchunk ^ ((row >> 1) & 7));
+    }
+    int zc = prow < ncols ? prow : ncols - 1;                        // z column of this thread's piece (32 rows x 8 chunks)
+    const int fl = zc / zs.C;
+    const float *zsrc = z_addr(zs, f_begin + fl, zc - fl * zs.C, 0);
+    const int zchunk = 4 * (pchunk ^ ((prow >> 1) & 7));
+    auto stage = [&](int buf, int t) {                               // t: 32-k slice of the segment
+        char *base = smem + buf * STAGE;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)                                 // (diagonal unit: rows 32r .. 32r+31 are zero from slice r+1 on:
+            glds16(diag && t > r ? lsrc[r] : lsrc[r] + t * SM_BK,   //  re-read slice 0 of the row -- an L2 hit -- instead)
+                   base + r * 4096 + w * 1024);
+        const int j = kbeg + t * SM_BK + zchunk;                     // 4 contiguous floats in every layout (j % 4 == 0)
+        glds16(zsrc + z_row_off(zs.layout, j >> 6) + (zs.layout == BNDM_Z_IMAGE32 ? (j & 31) : (j & 63)),
+               base + L_BYTES + w * 1024);
+    };
+    // slices of the diagonal unit above this wave's rows hold only zeros of L: skipped (all waves still stage them)
+    const int nslice = SM_KSEG / SM_BK;
+    const int mine = diag ? w + 1 : nslice;
+
+    f32x16 acc32;
+    f32x4v acc16[2][1];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc32[e] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 1; ++b) acc16[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    stage(0, 0);
+    stage(1, 1);
+    for (int t = 0; t < nslice; ++t) {
+        if (t + 1 < nslice) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // slice t landed, slice t+1 may fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const float *Lt = reinterpret_cast<const float *>(smem + (t & 1) * STAGE);
+        const float *Zt = reinterpret_cast<const float *>(smem + (t & 1) * STAGE + L_BYTES);
+        if (t < mine) {
+            if constexpr (W16) {
+                // 16x16x4: lane (i = l & 15, kq = l >> 4) holds 4 consecutive k of its row; MFMA e multiplies element e
+                const int i = l & 15, kq = l >> 4;
+#pragma unroll
+                for (int b16 = 0; b16 < 2; ++b16) {
+                    const int c = 4 * b16 + kq;
+                    const f32x4v zf = *reinterpret_cast<const f32x4v *>(Zt + i * SM_BK + 4 * (c ^ ((i >> 1) & 7)));
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int row = w * 32 + h * 16 + i;
+                        const f32x4v lf = *reinterpret_cast<const f32x4v *>(Lt + row * SM_BK + 4 * (c ^ ((row >> 1) & 7)));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc16[h][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf[e], lf[e], acc16[h][0], 0, 0, 0);
+                    }
+                }
+            } else {
+                const int q = l & 31, kh = l >> 5;
+                const int row = w * 32 + q;
+#pragma unroll
+                for (int s = 0; s < SM_BK / 8; ++s) {
+                    const int c = 2 * s + kh;
+                    const f32x4v lf = *reinterpret_cast<const f32x4v *>(Lt + row * SM_BK + 4 * (c ^ ((row >> 1) & 7)));
+                    const f32x4v zf = *reinterpret_cast<const f32x4v *>(Zt + q * SM_BK + 4 * (c ^ ((q >> 1) & 7)));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc32 = __builtin_amdgcn_mfma_f32_32x32x2f32(zf[e], lf[e], acc32, 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                            // buffer t & 1 may be overwritten
+        asm volatile("" ::: "memory");
+        if (t + 2 < nslice) stage(t & 1, t + 2);
+    }
+
+    // ---- D rows = z columns, D cols = L rows: contiguous stores along i ------------------------------------
+    float *pseg = part + (size_t)S * ncols * NPIX;
+    if constexpr (W16) {
+        const int i = l & 15, kq = l >> 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = 4 * kq + e;
+                if (col < ncols) pseg[(size_t)col * NPIX + i0 + w * 32 + h * 16 + i] = acc16[h][0][e];
+            }
+    } else {
+        const int q = l & 31, kh = l >> 5;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int col = (e & 3) + 8 * (e >> 2) + 4 * kh;
+            if (col < ncols) pseg[(size_t)col * NPIX + i0 + w * 32 + q] = acc32[e];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                   // (second unit of a diagonal pair re-uses the LDS buffers)
+    asm volatile("" ::: "memory");
+    }
+}
+
 #pragma clang fp contract(off)   // lerp evaluated as torch does: two rounded products, one add
 __global__ __launch_bounds__(256) void bluenoise_finish(const float *__restrict__ part, ZSrc zs,
                                                         const float *__restrict__ alpha,
@@ -168,7 +331,7 @@ __global__ __launch_bounds__(256) void bluenoise_finish(const float *__restrict_
                                                         float *__restrict__ noise_bn,
                                                         float *__restrict__ noise_wn, int ncols,
                                                         int b_begin, int b_count, int res, int mode,
-                                                        int dense) {
+                                                        int dense, int kseg) {
     const int C = zs.C;
     const size_t total = (size_t)b_count * C * res * res;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -201,9 +364,16 @@ __global__ __launch_bounds__(256) void bluenoise_finish(const float *__restrict_
         if (mode == BNDM_NOISE_SCRAMBLE) {
             out = wn;
         } else {
-            const int nseg = dense ? NSEG : ((i >> 6) >> 4) + 1;
+            const int nseg = dense ? NPIX / kseg : i / kseg + 1;
             float bn = part[(size_t)lc * NPIX + i];
-            for (int s = 1; s < nseg; ++s) bn = bn + part[((size_t)s * ncols + lc) * NPIX + i];
+            for (int s0 = 1; s0 < nseg; s0 += 31) {             // all slabs in flight at once; the sum keeps the segment order
+                float v[31];
+#pragma unroll
+                for (int k = 0; k < 31; ++k) v[k] = s0 + k < nseg ? part[((size_t)(s0 + k) * ncols + lc) * NPIX + i] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 31; ++k)
+                    if (s0 + k < nseg) bn = bn + v[k];
+            }
             if (noise_bn) noise_bn[idx] = bn;
             if (mode == BNDM_NOISE_BLEND) {
                 const float a = alpha[b];
@@ -241,7 +411,7 @@ using namespace bndm;
 extern "C" size_t bndm_bluenoise_workspace_bytes(int b_count, int C, int res) {
     if (b_count <= 0 || C <= 0) return 0;
     const size_t ncols = (size_t)b_count * C * (res == 128 ? 4 : 1);
-    return (size_t)NSEG * ncols * NPIX * sizeof(float);
+    return (size_t)(ncols <= 32 ? SM_NSEG : NSEG) * ncols * NPIX * sizeof(float);     // one slab per k segment
 }
 
 extern "C" int bndm_bluenoise(const float *L, int l_dense, const float *z, int z_layout,
@@ -274,7 +444,14 @@ extern "C" int bndm_bluenoise(const float *L, int l_dense, const float *z, int z
                      "bndm_bluenoise: workspace too small (%zu < %zu)", workspace_bytes,
                      bndm_bluenoise_workspace_bytes(b_count, C, res));
         int rc;
-        if (ncols <= 64) rc = launch_gemm<1>(L, zs, part, ncols, f_begin, l_dense ? 1 : 0, st);
+        if (ncols <= 32) {
+            const dim3 grid(l_dense ? 32 * 32 : 512);
+            if (ncols <= 16)
+                hipLaunchKernelGGL(bluenoise_small<true>, grid, dim3(256), 0, st, L, zs, part, ncols, f_begin, l_dense ? 1 : 0);
+            else
+                hipLaunchKernelGGL(bluenoise_small<false>, grid, dim3(256), 0, st, L, zs, part, ncols, f_begin, l_dense ? 1 : 0);
+            rc = launch_status("bluenoise_small");
+        } else if (ncols <= 64) rc = launch_gemm<1>(L, zs, part, ncols, f_begin, l_dense ? 1 : 0, st);
         else if (ncols <= 128) rc = launch_gemm<2>(L, zs, part, ncols, f_begin, l_dense ? 1 : 0, st);
         else rc = launch_gemm<3>(L, zs, part, ncols, f_begin, l_dense ? 1 : 0, st);
         if (rc) return rc;
@@ -282,6 +459,7 @@ extern "C" int bndm_bluenoise(const float *L, int l_dense, const float *z, int z
     const size_t total = (size_t)b_count * C * res * res;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(bluenoise_finish, dim3(blocks), dim3(256), 0, st, part, zs, alpha, noise, noise_bn,
-                       noise_wn, ncols, b_begin, b_count, res, mode, l_dense ? 1 : 0);
+                       noise_wn, ncols, b_begin, b_count, res, mode, l_dense ? 1 : 0,
+                       mode != BNDM_NOISE_SCRAMBLE && ncols <= 32 ? SM_KSEG : KSEG);
     return launch_status("bluenoise_finish");
 }

@@ -514,7 +514,8 @@ __global__ __launch_bounds__(256, 2) void conv_t32(const FusedArgs a, const int 
             constexpr int r = s >= 3 && s <= 7 && s - 3 < NFULL ? s - 3 : -1;
             // the phase is its own scheduling region: the group pattern below must only see this phase's instructions
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr ((ABL & 512) != 0) __builtin_amdgcn_s_setprio(1);
+            if constexpr (!(ABL & 512)) __builtin_amdgcn_s_setprio(1);      // two independent workgroups per SIMD: the MFMA
+                                                                           // phase of one outranks the other's DMA issue / VALU
             mma_refill(kcur, tnext, knext);
             xf_math(sc, pc);
             if constexpr (!(ABL & 1) && !(ABL & 4) && !(ABL & 32)) {
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void conv_t32(const FusedArgs a, const int 
                     __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                         // VALU in the shadow
                 }
             }
-            if constexpr ((ABL & 512) != 0) __builtin_amdgcn_s_setprio(0);
+            if constexpr (!(ABL & 512)) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         };
         auto mark = [&](int t, int k) {
