@@ -55,6 +55,9 @@ def main():
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "pmc_traffic.json"), "w") as f:      # gpurun merges gpurun_out/ back
+        json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
 
 
