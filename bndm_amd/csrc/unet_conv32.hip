@@ -75,22 +75,25 @@ struct Chunk {
 // dispatcher is observed to fill the CUs (a speed assumption only) -- start `stagger` shader cycles late, so that the two
 // workgroups of a CU run out of phase: one's prologue / epilogue (HBM-bound, launch-wide bursts if everybody is in
 // step) falls into the other's MFMA time.  Later workgroups inherit the offset from the slot they take over.
-template <typename T, int TH, int ABL>
-__global__ __launch_bounds__(256, 2) void conv_t32(const FusedArgs a, const int tiles_x, const int tps, const int ntn,
+// NW: waves per workgroup.  4: one wave per SIMD and workgroup, 64 x 128 wave tiles, two workgroups per CU -- for grids
+// of at least two workgroups per CU.  8: 4(M) x 2(N) waves of 64 x 64, two waves per SIMD from ONE workgroup -- for
+// the smaller grids (32x32 and 16x16 layers at batch 64), where a CU would otherwise host a single 4-wave workgroup.
+template <typename T, int TH, int ABL, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const int tiles_x, const int tps, const int ntn,
                                                    const int nsteps_w, const int stagger, unsigned *__restrict__ dbg) {
     using v8 = typename TT<T>::v8;
     using v4 = typename TT<T>::v4;
     using v2 = typename TT<T>::v2;
     constexpr int TW = 16, PW = TW + 2, PH = TH + 2;
-    constexpr int NT = 256, NW = 4;
+    constexpr int NT = NW * 64, WAVES_N = NW / 4;
     constexpr int NPIECE = PH * PW * 4;                // 16-byte pieces per patch chunk
-    constexpr int NWP = (128 * 64) / (NT * 16);        // weight-tile pieces per thread (2)
+    constexpr int NWP = (128 * 64) / (NT * 16);        // weight-tile pieces per thread (2 or 1)
     constexpr int NROUND = (NPIECE + NT - 1) / NT;     // patch DMA rounds per chunk (the last one may be partial)
     constexpr int NREMW = (NPIECE - (NROUND - 1) * NT + 63) / 64;    // waves with pieces in the last round
     constexpr int PATCH_BYTES = (NROUND - 1) * NT * 16 + NREMW * 1024;
     constexpr int BM = TH * TW;
     constexpr int TM = TH / 8;                         // 32-pixel MFMA tiles per wave along M (2 rows x 16 columns each)
-    constexpr int TN = 4;
+    constexpr int TN = 4 / WAVES_N;                    // 32-channel MFMA tiles per wave along N
     constexpr int WSTAGES = 4, W_BYTES = 128 * 64;
     constexpr int OFF_W = 2 * PATCH_BYTES;
     constexpr int OFF_SS = OFF_W + WSTAGES * W_BYTES;
@@ -266,7 +269,8 @@ __global__ __launch_bounds__(256, 2) void conv_t32(const FusedArgs a, const int 
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int q = l & 31, kh = l >> 5;
-    const int row_base = w * (TH / NW);
+    const int wm = w & 3, wn = w >> 2;                 // wave's pixel-row group / channel half
+    const int row_base = wm * (TH / 4);
     const int lr = q >> 4, lcx = q & 15;
 
     // ---- fragment addresses ---------------------------------------------------------------------------
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv_t32(const FusedArgs a, const int 
     // The second k16 slice (ks = 1) flips bit 1 of the slot index, i.e. bit 5 of the byte address: one v_xor per
     // fragment base instead of a second set of address registers.
     int wa, pa[2][3];
-    wa = OFF_W + q * 64 + ((kh ^ ((q >> 2) & 3)) << 4);
+    wa = OFF_W + (wn * TN * 32 + q) * 64 + ((kh ^ ((q >> 2) & 3)) << 4);
 #pragma unroll
     for (int kyp = 0; kyp < 2; ++kyp)
 #pragma unroll
@@ -331,8 +335,8 @@ __global__ __launch_bounds__(256, 2) void conv_t32(const FusedArgs a, const int 
         if (!a.gn_p1) {
             const __amdgpu_buffer_rsrc_t srs =
                 uniform_rsrc(a.ss ? a.ss + (size_t)b * 2 * a.ssC : (const float *)a.zeros, a.ss ? 2 * a.ssC * 4 : 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_ptr_t)(smem + OFF_SS + w * 1024), 16, (unsigned)(tid * 16),
-                                                     0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lds_ptr_t)(smem + (w < 4 ? OFF_SS + w * 1024 : OFF_DUMP)), 16,
+                                                     (unsigned)(tid * 16), 0, 0, 0);
         }
         // the tile's additive row (the launcher passes bias OR the time-embedding row, which has the bias folded in):
         // 32 pieces by the first lanes of wave 0 (its other lanes and the other waves read zeros into the dead slot,
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(256, 2) void conv_t32(const FusedArgs a, const int 
             const int buf = n & 1;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const int wb = OFF_W + buf * W_BYTES + q * 64 + (((2 * ks + kh) ^ ((q >> 2) & 3)) << 4);
+                const int wb = OFF_W + buf * W_BYTES + (wn * TN * 32 + q) * 64 + (((2 * ks + kh) ^ ((q >> 2) & 3)) << 4);
                 const int pb = buf * PATCH_BYTES + ((row_base + lr + 1) * PW + lcx + 1) * 64 +
                                (((2 * ks + kh) ^ t32_patch_key(row_base + lr + 1, lcx + 1)) << 4);
                 v8 ga[TN], gb[TM];
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(256, 2) void conv_t32(const FusedArgs a, const int 
     for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            addv[i][g] = *reinterpret_cast<const f32x4 *>(smem + OFF_BIAS + (i * 32 + 8 * g + 4 * kh) * 4);
+            addv[i][g] = *reinterpret_cast<const f32x4 *>(smem + OFF_BIAS + (wn * TN * 32 + i * 32 + 8 * g + 4 * kh) * 4);
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int prow = row_base + 2 * j + lr;
@@ -672,7 +676,7 @@ __global__ __launch_bounds__(256, 2) void conv_t32(const FusedArgs a, const int 
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int cl = i * 32 + 8 * g + 4 * kh;                   // channel inside the block
+                const int cl = wn * TN * 32 + i * 32 + 8 * g + 4 * kh;    // channel inside the block
                 v4 ov;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ov[e] = (T)(acc[i][j][4 * g + e] + addv[i][g][e]);
@@ -733,36 +737,41 @@ __global__ __launch_bounds__(256, 2) void conv_t32(const FusedArgs a, const int 
             }
         }
         __syncthreads();
-        const float t = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
-        a.stats[((size_t)(b * tps + tin) * a.Cout + n0) * 2 + tid] = t;
+        if (tid < 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) t += red[wv * 256 + tid];
+            a.stats[((size_t)(b * tps + tin) * a.Cout + n0) * 2 + tid] = t;
+        }
     }
     life(5);
 }
 
-template <int TH> constexpr int t32_smem_bytes() {
-    constexpr int NPIECE = (TH + 2) * 18 * 4, NROUND = (NPIECE + 255) / 256;
-    constexpr int NREMW = (NPIECE - (NROUND - 1) * 256 + 63) / 64;
-    constexpr int PATCH_BYTES = (NROUND - 1) * 4096 + NREMW * 1024;
+template <int TH, int NW> constexpr int t32_smem_bytes() {
+    constexpr int NT = NW * 64;
+    constexpr int NPIECE = (TH + 2) * 18 * 4, NROUND = (NPIECE + NT - 1) / NT;
+    constexpr int NREMW = (NPIECE - (NROUND - 1) * NT + 63) / 64;
+    constexpr int PATCH_BYTES = (NROUND - 1) * NT * 16 + NREMW * 1024;
     constexpr int main_bytes = 2 * PATCH_BYTES + 4 * 8192 + T32_SS_BYTES + T32_MAX_CHUNKS * 16 + 512 + 1024;
-    constexpr int epi_bytes = TH * 16 * 256 + 4 * 128 * 2 * 4;
+    constexpr int epi_bytes = TH * 16 * 256 + NW * 128 * 2 * 4;
     return main_bytes > epi_bytes ? main_bytes : epi_bytes;
 }
 
-template <typename T, int TH, int ABL>
+template <typename T, int TH, int ABL, int NW = 4>
 int launch_t32_t(const FusedArgs &a, hipStream_t st) {
-    constexpr int smem = t32_smem_bytes<TH>();
+    constexpr int smem = t32_smem_bytes<TH, NW>();
     static_assert(smem <= 80 * 1024, "LDS budget: two workgroups per CU");
     static bool attr = false;
     if (!attr) {
-        BNDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_t32<T, TH, ABL>),
+        BNDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_t32<T, TH, ABL, NW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr = true;
         if (getenv("BNDM_T32_DEBUG")) {
             int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&conv_t32<T, TH, ABL>),
-                                                               256, smem);
-            fprintf(stderr, "[bndm] conv_t32<TH=%d>: %d B of LDS, %d resident workgroups per CU (occupancy query)\n", TH,
-                    smem, nb);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&conv_t32<T, TH, ABL, NW>),
+                                                               NW * 64, smem);
+            fprintf(stderr, "[bndm] conv_t32<TH=%d, NW=%d>: %d B of LDS, %d resident workgroups per CU (occupancy query)\n",
+                    TH, NW, smem, nb);
         }
     }
     const int tiles_x = a.W / 16, tiles_y = a.H / TH, tps = tiles_x * tiles_y, ntn = a.Cout / 128;
@@ -771,14 +780,14 @@ int launch_t32_t(const FusedArgs &a, hipStream_t st) {
     dim3 grid(a.B * tps * ntn);
     // half a workgroup's MFMA time (16 MFMAs of 32 cycles per K-step and wave; twice that while two workgroups share)
     static const int stagger_pct = getenv("BNDM_T32_STAGGER") ? atoi(getenv("BNDM_T32_STAGGER")) : 50;
-    const int stagger = grid.x > 256 ? (int)((long long)nsteps * 1024 * (TH / 8) / 2 * stagger_pct / 100) : 0;
+    const int stagger = NW == 4 && grid.x > 256 ? (int)((long long)nsteps * 1024 * (TH / 8) / 2 * stagger_pct / 100) : 0;
     unsigned *dbg = nullptr;
     if constexpr ((ABL & 64) != 0) {
         static unsigned *buf = nullptr;
         if (!buf) BNDM_CHECK_HIP(hipMalloc(&buf, (4 * 9 * 6 + 32) * sizeof(unsigned)));
         dbg = buf;
     }
-    hipLaunchKernelGGL((conv_t32<T, TH, ABL>), grid, dim3(256), smem, st, a, tiles_x, tps, ntn, nsteps, stagger, dbg);
+    hipLaunchKernelGGL((conv_t32<T, TH, ABL, NW>), grid, dim3(NW * 64), smem, st, a, tiles_x, tps, ntn, nsteps, stagger, dbg);
     if constexpr ((ABL & 64) != 0) {
         // profiling aid: dump the marks of 8-chunk launches (the K = 2304 layers) as text
         int n9 = 0;
@@ -862,8 +871,12 @@ std::vector<float> pack_weights_t32(const FusedSeg *seg, int nseg, int Cout,
 
 int launch_conv_t32(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
     static const int abl = getenv("BNDM_ABLATE") ? atoi(getenv("BNDM_ABLATE")) : 0;
+    static const int nw_env = getenv("BNDM_T32_NW") ? atoi(getenv("BNDM_T32_NW")) : 0;
+    // two 4-wave workgroups per CU need a grid of at least ~two per CU; smaller grids get 8-wave workgroups
+    const long long nblk = (long long)a.B * (a.H / TH) * (a.W / 16) * (a.Cout / 128);
+    const int nw = nw_env ? nw_env : (nblk >= 448 ? 4 : 8);
     if (dtype == BNDM_DTYPE_F16) {
-        if (abl && TH == 16) {
+        if (abl && TH == 16 && nw == 4) {
             switch (abl) {
                 case 1: return launch_t32_t<_Float16, 16, 1>(a, st);
                 case 2: return launch_t32_t<_Float16, 16, 2>(a, st);
@@ -877,8 +890,10 @@ int launch_conv_t32(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
                 default: break;
             }
         }
+        if (nw == 8) return TH == 16 ? launch_t32_t<_Float16, 16, 0, 8>(a, st) : launch_t32_t<_Float16, 8, 0, 8>(a, st);
         return TH == 16 ? launch_t32_t<_Float16, 16, 0>(a, st) : launch_t32_t<_Float16, 8, 0>(a, st);
     }
+    if (nw == 8) return TH == 16 ? launch_t32_t<__bf16, 16, 0, 8>(a, st) : launch_t32_t<__bf16, 8, 0, 8>(a, st);
     return TH == 16 ? launch_t32_t<__bf16, 16, 0>(a, st) : launch_t32_t<__bf16, 8, 0>(a, st);
 }
 
