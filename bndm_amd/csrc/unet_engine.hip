@@ -1666,13 +1666,33 @@ extern "C" int bndm_unet_profile(bndm_unet *h, const float *sample, const float 
             if (h->ops[k].cls == OPC_CONV) conv_ms += m;
         }
     }
+    // profiling aid (BNDM_PROFILE_HOT=1): every op repeated 10x back to back right after a forward -- its operands and
+    // weights are then cache-resident, which separates a kernel's own cost from cold-HBM / first-touch effects
+    std::vector<double> hot_ms(nops, 0.0);
+    if (getenv("BNDM_PROFILE_HOT")) {
+        RunCtx rp{B, st, sample, nullptr, timesteps, out};
+        if ((rc = run_forward(h, rp))) return rc;
+        for (size_t k = 0; k < nops; ++k) {
+            if ((rc = h->ops[k].run(rp))) return rc;
+            BNDM_CHECK_HIP(hipEventRecord(t0, st));
+            for (int i = 0; i < 10; ++i)
+                if ((rc = h->ops[k].run(rp))) return rc;
+            BNDM_CHECK_HIP(hipEventRecord(t1, st));
+            BNDM_CHECK_HIP(hipEventSynchronize(t1));
+            float m = 0;
+            BNDM_CHECK_HIP(hipEventElapsedTime(&m, t0, t1));
+            hot_ms[k] = m / 10;
+        }
+    }
     if (const char *dump = getenv("BNDM_PROFILE_DUMP")) {
         FILE *f = fopen(dump, "w");
         if (f) {
             for (size_t k = 0; k < nops; ++k) {
                 const double ms_k = op_ms[k] / iters, fl = h->ops[k].flops_per_sample * B;
-                fprintf(f, "%3zu %8.4f ms %8.1f TF/s  %s\n", k, ms_k, ms_k > 0 ? fl / (ms_k * 1e-3) / 1e12 : 0.0,
+                fprintf(f, "%3zu %8.4f ms %8.1f TF/s  %s", k, ms_k, ms_k > 0 ? fl / (ms_k * 1e-3) / 1e12 : 0.0,
                         h->ops[k].name.c_str());
+                if (hot_ms[k] > 0) fprintf(f, "   [hot x10: %.4f ms]", hot_ms[k]);
+                fprintf(f, "\n");
             }
             fclose(f);
         }
