@@ -297,7 +297,7 @@ def main():
                                    B, 3, C.byref(prof), _lib.current_stream_ptr())
         _lib.check(rc, "bndm_unet_profile")
         from bndm_amd.unet import engine_ops
-        dom = sorted({k for k, _, _ in engine_ops(h) if k.startswith("conv_t32<TH=16")})
+        dom = sorted({k for k, _, _ in engine_ops(h) if k == "conv_t32<TH=16>"})
         kernel_tag = dom[0] if dom else "conv_t32"
         achieved = prof.dom_flops / (prof.ms_dom * 1e-3) / 1e12 if prof.ms_dom > 0 else 0.0
         conv_all = prof.conv_flops / (prof.ms_conv * 1e-3) / 1e12

@@ -78,7 +78,10 @@ struct Chunk {
 // NW: waves per workgroup.  4: one wave per SIMD and workgroup, 64 x 128 wave tiles, two workgroups per CU -- for grids
 // of at least two workgroups per CU.  8: 4(M) x 2(N) waves of 64 x 64, two waves per SIMD from ONE workgroup -- for
 // the smaller grids (32x32 and 16x16 layers at batch 64), where a CU would otherwise host a single 4-wave workgroup.
-template <typename T, int TH, int ABL, int NW>
+// NCO: output channels per workgroup.  128: the ResnetBlock2D / Upsample2D convolutions (16-bit NHWC output + GroupNorm
+// partial sums).  32: the network head -- conv_norm_out + SiLU + conv_out (iadb_bn.py:205-282: out_channels 3 / 6 / 8),
+// written as the caller's fp32 NCHW tensor; the loop is then bound by the one read + normalisation of the input.
+template <typename T, int TH, int ABL, int NW, int NCO>
 __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const int tiles_x, const int tps, const int ntn,
                                                    const int nsteps_w, const int stagger, unsigned *__restrict__ dbg) {
     using v8 = typename TT<T>::v8;
@@ -87,14 +90,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
     constexpr int TW = 16, PW = TW + 2, PH = TH + 2;
     constexpr int NT = NW * 64, WAVES_N = NW / 4;
     constexpr int NPIECE = PH * PW * 4;                // 16-byte pieces per patch chunk
-    constexpr int NWP = (128 * 64) / (NT * 16);        // weight-tile pieces per thread (2 or 1)
+    constexpr int NWP = (NCO * 64) / (NT * 16) > 0 ? (NCO * 64) / (NT * 16) : 1;   // weight-tile DMAs per thread (2 or 1)
+    constexpr int NWW = NCO * 64 / 1024 < NW ? NCO * 64 / 1024 : NW;              // waves that carry weight pieces
     constexpr int NROUND = (NPIECE + NT - 1) / NT;     // patch DMA rounds per chunk (the last one may be partial)
     constexpr int NREMW = (NPIECE - (NROUND - 1) * NT + 63) / 64;    // waves with pieces in the last round
     constexpr int PATCH_BYTES = (NROUND - 1) * NT * 16 + NREMW * 1024;
     constexpr int BM = TH * TW;
     constexpr int TM = TH / 8;                         // 32-pixel MFMA tiles per wave along M (2 rows x 16 columns each)
-    constexpr int TN = 4 / WAVES_N;                    // 32-channel MFMA tiles per wave along N
-    constexpr int WSTAGES = 4, W_BYTES = 128 * 64;
+    constexpr int TN = NCO / 32 / WAVES_N;             // 32-channel MFMA tiles per wave along N
+    static_assert(TN >= 1, "wave tiling");
+    constexpr int WSTAGES = 4, W_BYTES = NCO * 64;
     constexpr int OFF_W = 2 * PATCH_BYTES;
     constexpr int OFF_SS = OFF_W + WSTAGES * W_BYTES;
     constexpr int OFF_TAB = OFF_SS + T32_SS_BYTES;     // chunk descriptors, 16 B each
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
     const int b = __builtin_amdgcn_readfirstlane(mt / tps), tin = __builtin_amdgcn_readfirstlane(mt - b * tps);
     const int ty = tin / tiles_x, tx = tin - ty * tiles_x;
     const int y0 = __builtin_amdgcn_readfirstlane(ty * TH), x0 = __builtin_amdgcn_readfirstlane(tx * TW);
-    const int n0 = __builtin_amdgcn_readfirstlane(nt * 128);
+    const int n0 = __builtin_amdgcn_readfirstlane(nt * NCO);
     const int H = a.H, Wd = a.W;
     const int lgH = 31 - __builtin_clz(H), lgW = 31 - __builtin_clz(Wd);
 
@@ -252,12 +257,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
     const __amdgpu_buffer_rsrc_t wrs =
         uniform_rsrc((const char *)a.Wgt + (size_t)nt * nsteps_w * W_BYTES, nsteps_w * W_BYTES);
     auto w_issue = [&](int slot, int step) {
-        char *base = smem + OFF_W + slot * W_BYTES + w * 1024;
-        const int so = __builtin_amdgcn_readfirstlane(step * W_BYTES);
+        char *base = smem + (w < NWW ? OFF_W + slot * W_BYTES + w * 1024 : OFF_DUMP);   // (narrow tiles: the other waves' DMA
+        const int so = __builtin_amdgcn_readfirstlane(step * W_BYTES);                  //  reads past the tile = zeros, dumped)
 #pragma unroll
         for (int i = 0; i < NWP; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(base + i * (NT * 16)), 16,
-                                                     (unsigned)(tid * 16 + i * (NT * 16)), so, 0, 0);
+                                                     w < NWW ? (unsigned)(tid * 16 + i * (NT * 16)) : 0x80000000u, so, 0, 0);
     };
 
     f32x16 acc[TN][TM];
@@ -342,7 +347,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
         // 32 pieces by the first lanes of wave 0 (its other lanes and the other waves read zeros into the dead slot,
         // which starts right behind the row)
         const float *row = a.temb ? a.temb + (size_t)b * a.temb_bstride + a.temb_off + n0 : a.bias ? a.bias + n0 : nullptr;
-        const __amdgpu_buffer_rsrc_t brs = uniform_rsrc(row ? row : (const float *)a.zeros, row ? 512 : 0);
+        const __amdgpu_buffer_rsrc_t brs =
+            uniform_rsrc(row ? row : (const float *)a.zeros, row ? (a.Cout - n0 < NCO ? a.Cout - n0 : NCO) * 4 : 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lds_ptr_t)(smem + (w == 0 ? OFF_BIAS : OFF_DUMP)), 16,
                                                  (unsigned)(tid * 16), 0, 0, 0);
     }
@@ -377,15 +383,18 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
                 const bool first = c < C1;
                 const float *p = first ? a.gn_p1 : a.gn_p2;
                 const int ns = first ? a.gn_ns1 : a.gn_ns2, Cs = first ? C1 : C - C1, cc = first ? c : c - C1;
-                float2 v[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    v[k] = k < ns ? *reinterpret_cast<const float2 *>(p + ((size_t)(b * ns + k) * Cs + cc) * 2) : float2{0.f, 0.f};
                 float s = 0.f, q2 = 0.f;
+                for (int k0 = 0; k0 < ns; k0 += 16) {        // 16 slabs in flight; the sums keep the slab order
+                    float2 v[16];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    s += v[k].x;
-                    q2 += v[k].y;
+                    for (int k = 0; k < 16; ++k)
+                        v[k] = k0 + k < ns ? *reinterpret_cast<const float2 *>(p + ((size_t)(b * ns + k0 + k) * Cs + cc) * 2)
+                                           : float2{0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        s += v[k].x;
+                        q2 += v[k].y;
+                    }
                 }
                 cs[c] = s;
                 css[c] = q2;
@@ -660,6 +669,26 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
     }
 
     life(3);
+    if constexpr (NCO == 32) {
+        // ---- head epilogue: bias, fp32 NCHW (lane = one pixel, 16 of the 32 padded channels) ------------------------
+        float *o = (float *)a.out;
+        const size_t HWs = (size_t)H * Wd;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int prow = row_base + 2 * j + lr;
+            const size_t pix = (size_t)(y0 + prow) * Wd + x0 + lcx;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = 8 * g + 4 * kh + e;
+                    if (co < a.Cout)
+                        o[((size_t)b * a.Cout + co) * HWs + pix] =
+                            acc[0][j][4 * g + e] + *reinterpret_cast<const float *>(smem + OFF_BIAS + co * 4);
+                }
+        }
+        return;
+    }
     // ---- epilogue 1: bias + time embedding -> 16-bit tile in LDS ([BM][128 ch], swizzled) ---------------
     char *stg = smem;
     f32x4 addv[TN][4];
@@ -747,34 +776,34 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
     life(5);
 }
 
-template <int TH, int NW> constexpr int t32_smem_bytes() {
+template <int TH, int NW, int NCO = 128> constexpr int t32_smem_bytes() {
     constexpr int NT = NW * 64;
     constexpr int NPIECE = (TH + 2) * 18 * 4, NROUND = (NPIECE + NT - 1) / NT;
     constexpr int NREMW = (NPIECE - (NROUND - 1) * NT + 63) / 64;
     constexpr int PATCH_BYTES = (NROUND - 1) * NT * 16 + NREMW * 1024;
-    constexpr int main_bytes = 2 * PATCH_BYTES + 4 * 8192 + T32_SS_BYTES + T32_MAX_CHUNKS * 16 + 512 + 1024;
-    constexpr int epi_bytes = TH * 16 * 256 + NW * 128 * 2 * 4;
+    constexpr int main_bytes = 2 * PATCH_BYTES + 4 * NCO * 64 + T32_SS_BYTES + T32_MAX_CHUNKS * 16 + 512 + 1024;
+    constexpr int epi_bytes = NCO == 128 ? TH * 16 * 256 + NW * 128 * 2 * 4 : 0;
     return main_bytes > epi_bytes ? main_bytes : epi_bytes;
 }
 
-template <typename T, int TH, int ABL, int NW = 4>
+template <typename T, int TH, int ABL, int NW = 4, int NCO = 128>
 int launch_t32_t(const FusedArgs &a, hipStream_t st) {
-    constexpr int smem = t32_smem_bytes<TH, NW>();
+    constexpr int smem = t32_smem_bytes<TH, NW, NCO>();
     static_assert(smem <= 80 * 1024, "LDS budget: two workgroups per CU");
     static bool attr = false;
     if (!attr) {
-        BNDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_t32<T, TH, ABL, NW>),
+        BNDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_t32<T, TH, ABL, NW, NCO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr = true;
         if (getenv("BNDM_T32_DEBUG")) {
             int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&conv_t32<T, TH, ABL, NW>),
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&conv_t32<T, TH, ABL, NW, NCO>),
                                                                NW * 64, smem);
             fprintf(stderr, "[bndm] conv_t32<TH=%d, NW=%d>: %d B of LDS, %d resident workgroups per CU (occupancy query)\n",
                     TH, NW, smem, nb);
         }
     }
-    const int tiles_x = a.W / 16, tiles_y = a.H / TH, tps = tiles_x * tiles_y, ntn = a.Cout / 128;
+    const int tiles_x = a.W / 16, tiles_y = a.H / TH, tps = tiles_x * tiles_y, ntn = (a.Cout + NCO - 1) / NCO;
     int nsteps = 0;
     for (int i = 0; i < a.nseg; ++i) nsteps += a.seg[i].taps * (a.seg[i].C / 32);
     dim3 grid(a.B * tps * ntn);
@@ -787,7 +816,7 @@ int launch_t32_t(const FusedArgs &a, hipStream_t st) {
         if (!buf) BNDM_CHECK_HIP(hipMalloc(&buf, (4 * 9 * 6 + 32) * sizeof(unsigned)));
         dbg = buf;
     }
-    hipLaunchKernelGGL((conv_t32<T, TH, ABL, NW>), grid, dim3(NW * 64), smem, st, a, tiles_x, tps, ntn, nsteps, stagger, dbg);
+    hipLaunchKernelGGL((conv_t32<T, TH, ABL, NW, NCO>), grid, dim3(NW * 64), smem, st, a, tiles_x, tps, ntn, nsteps, stagger, dbg);
     if constexpr ((ABL & 64) != 0) {
         // profiling aid: dump the marks of 8-chunk launches (the K = 2304 layers) as text
         int n9 = 0;
@@ -835,7 +864,8 @@ bool conv_t32_supports(const FusedArgs &a) {
         if ((long long)a.B * px * a.seg[i].C * 2 >= (1LL << 31)) return false;
     }
     if (a.ss && 2 * a.ssC * 4 > T32_SS_BYTES) return false;
-    return a.nseg >= 1 && a.seg[0].taps == 9 && nchunks <= T32_MAX_CHUNKS && a.Cout % 128 == 0 && a.W % 16 == 0;
+    return a.nseg >= 1 && a.seg[0].taps == 9 && nchunks <= T32_MAX_CHUNKS && a.W % 16 == 0 &&
+           (a.out_nchw32 ? a.Cout <= 32 && !a.resid && !a.stats && !a.temb : a.Cout % 128 == 0);
 }
 
 int conv_t32_tiles_per_sample(int TH, int H, int W) { return (H / TH) * (W / 16); }
@@ -844,11 +874,11 @@ int conv_t32_tiles_per_sample(int TH, int H, int W) { return (H / TH) * (W / 16)
 // K-steps run over the 3x3 segments' 32-channel chunks x 9 taps, then over the 1x1 segments' chunks, and slot j of row
 // r holds channels 8 (j ^ ((r >> 2) & 3)) .. +7 of the step.  `w_of(seg, co, c, tap)` returns the fp32 weight.
 std::vector<float> pack_weights_t32(const FusedSeg *seg, int nseg, int Cout,
-                                    const std::function<float(int, int, int, int)> &w_of) {
+                                    const std::function<float(int, int, int, int)> &w_of, int rows) {
     int nsteps = 0;
     for (int i = 0; i < nseg; ++i) nsteps += seg[i].taps * (seg[i].C / 32);
-    const int ntn = (Cout + 127) / 128;
-    std::vector<float> out((size_t)ntn * nsteps * 128 * 32, 0.f);
+    const int ntn = (Cout + rows - 1) / rows;
+    std::vector<float> out((size_t)ntn * nsteps * rows * 32, 0.f);
     int step = 0;
     for (int pass = 0; pass < 2; ++pass)                 // 3x3 segments first
         for (int i = 0; i < nseg; ++i) {
@@ -856,12 +886,12 @@ std::vector<float> pack_weights_t32(const FusedSeg *seg, int nseg, int Cout,
             for (int ci = 0; ci < seg[i].C / 32; ++ci)
                 for (int t = 0; t < seg[i].taps; ++t, ++step)
                     for (int nt = 0; nt < ntn; ++nt)
-                        for (int r = 0; r < 128; ++r) {
-                            const int co = nt * 128 + r;
+                        for (int r = 0; r < rows; ++r) {
+                            const int co = nt * rows + r;
                             if (co >= Cout) continue;
                             for (int j = 0; j < 4; ++j) {
                                 const int s = j ^ ((r >> 2) & 3);
-                                float *dst = &out[(((size_t)nt * nsteps + step) * 128 + r) * 32 + j * 8];
+                                float *dst = &out[(((size_t)nt * nsteps + step) * rows + r) * 32 + j * 8];
                                 for (int e = 0; e < 8; ++e) dst[e] = w_of(i, co, ci * 32 + s * 8 + e, t);
                             }
                         }
@@ -873,6 +903,11 @@ int launch_conv_t32(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
     static const int abl = getenv("BNDM_ABLATE") ? atoi(getenv("BNDM_ABLATE")) : 0;
     static const int nw_env = getenv("BNDM_T32_NW") ? atoi(getenv("BNDM_T32_NW")) : 0;
     // two 4-wave workgroups per CU need a grid of at least ~two per CU; smaller grids get 8-wave workgroups
+    if (a.out_nchw32) {                              // network head: 32-channel tiles, fp32 NCHW output
+        if (dtype == BNDM_DTYPE_F16)
+            return TH == 16 ? launch_t32_t<_Float16, 16, 0, 4, 32>(a, st) : launch_t32_t<_Float16, 8, 0, 4, 32>(a, st);
+        return TH == 16 ? launch_t32_t<__bf16, 16, 0, 4, 32>(a, st) : launch_t32_t<__bf16, 8, 0, 4, 32>(a, st);
+    }
     const long long nblk = (long long)a.B * (a.H / TH) * (a.W / 16) * (a.Cout / 128);
     const int nw = nw_env ? nw_env : (nblk >= 448 ? 4 : 8);
     if (dtype == BNDM_DTYPE_F16) {

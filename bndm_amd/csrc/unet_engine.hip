@@ -440,7 +440,7 @@ struct Builder {
         g.HW = HW;
         g.gamma = gamma;
         g.beta = beta;
-        g.inkernel = use_gn_inkernel && a1.nslab <= 16 && (!x2 || a2.nslab <= 16) && C <= 512;
+        g.inkernel = use_gn_inkernel && a1.nslab <= 32 && (!x2 || a2.nslab <= 32) && C <= 512;
         if (g.inkernel) return g;
         h->grow(h->s_ss, (size_t)h->cfg.max_batch * 2 * C * 4);
         cur_name = S("gnfn %-44s C=%-4d %dx%d", pname.c_str(), C, x1.H, x1.W);
@@ -517,7 +517,8 @@ struct Builder {
     }
     void conv_fused(const std::vector<FIn> &ins, const std::vector<WSeg> &ws, const GnSpec *gs, bool silu,
                     const float *bias, int temb_off, const Act *resid, const Act &out, bool want_stats,
-                    const std::string &label) {
+                    const std::string &label, bool head = false) {
+        // head: out.slot < 0 -- the result is the caller's fp32 NCHW tensor (conv_out), out.C <= 32 real channels
         const bool normed = gs != nullptr;
         const int ssC = gs ? gs->C1 + gs->C2 : 0;
         const GnSpec g = gs ? *gs : GnSpec{};
@@ -549,11 +550,12 @@ struct Builder {
         a.zeros = h->zeros;
         // 256-pixel tiles unless that leaves workgroup slots idle at this handle's batch size
         int TH = out.H >= 32 ? 16 : 8;
-        const long long tiles16 = (long long)h->cfg.max_batch * (out.H / 16) * (out.W / 16) * (out.C / 128);
+        const long long tiles16 = (long long)h->cfg.max_batch * (out.H / 16) * (out.W / 16) * (head ? 1 : out.C / 128);
         static const int th16_min = getenv("BNDM_TH16_MIN") ? atoi(getenv("BNDM_TH16_MIN")) : 192;
         if (TH == 16 && tiles16 < th16_min) TH = 8;
         {
             a.Ktot = Ktot;
+            a.out_nchw32 = head ? 1 : 0;
             a.B = h->cfg.max_batch;
             a.ss = normed ? (const float *)h->zeros : nullptr;
             if (!conv_t32_supports(a)) {
@@ -564,7 +566,7 @@ struct Builder {
             const std::vector<float> wp = pack_weights_t32(a.seg, a.nseg, out.C, [&](int si, int co, int c, int t) {
                 const WSeg &w = ws[si];
                 return (*w.w)[((size_t)co * w.cin_total + w.c_begin + c) * w.taps + t];
-            });
+            }, head ? 32 : 128);
             if ((rc = upload_16(h, wp, &Wp))) return;
         }
         a.Wgt = Wp;
@@ -572,7 +574,7 @@ struct Builder {
         const int rs = resid ? resid->slot : -1, so = out.slot;
         int pst = -1;
         if (want_stats) pst = new_stats(out, conv_t32_tiles_per_sample(TH, out.H, out.W)).pslot;
-        else stats_of.erase(out.slot);
+        else if (!head) stats_of.erase(out.slot);
         cur_name = S("cnvF %-44s K=%-5d N=%-4d %dx%d", label.c_str(), Ktot, out.C, out.H, out.W);
         double abytes = 2.0 * out.C * out.H * out.W * (resid ? 2 : 1);
         for (const FIn &f : ins) abytes += 2.0 * f.a.C * f.a.H * f.a.W;
@@ -597,12 +599,12 @@ struct Builder {
             c.temb = temb_off >= 0 ? (r.tp_row ? r.tp_row : (const float *)hh->P(hh->s_tp)) : nullptr;
             c.temb_bstride = r.tp_row ? 0 : hh->ntemb;
             c.resid = rs >= 0 ? hh->P(rs) : nullptr;
-            c.out = hh->P(so);
+            c.out = head ? (void *)r.out : hh->P(so);
             c.stats = pst >= 0 ? (float *)hh->P(pst) : nullptr;
             return launch_conv_t32(hh->dtype(), TH, c, r.st);
         });
-        h->ops[op_index].dominant = TH == 16;
-        h->ops[op_index].kernel = S("conv_t32<TH=%d>", TH);
+        h->ops[op_index].dominant = TH == 16 && !head;
+        h->ops[op_index].kernel = S(head ? "conv_t32<TH=%d,N=32>" : "conv_t32<TH=%d>", TH);
         h->ops[op_index].bytes_per_sample = abytes;
         h->ops[op_index].bytes_fixed = wbytes;
     }
@@ -1044,39 +1046,14 @@ struct Builder {
             }
         }
         {
+            // decoder.conv_norm_out + SiLU + decoder.conv_out in one conv_t32 launch (fp32 NCHW images)
             const int C0 = x.C, RO = x.H;
-            Act y = scratch(h->s_y, C0, RO, RO);
-            group_norm(x, nullptr, "decoder.conv_norm_out", true, y);
+            const GnSpec g = gn_table(x, nullptr, "decoder.conv_norm_out");
             if (rc) return rc;
-            const void *Wp;
-            int K;
-            rc = pack_conv_weight(h, {WSeg{&h->hp("decoder.conv_out.weight"), C0, 0, C0, 9}}, c.out_channels, 32, &Wp, &K);
+            conv_fused({FIn{x, 9, 0, 0}}, {WSeg{&h->hp("decoder.conv_out.weight"), C0, 0, C0, 9}}, &g, true,
+                       bias_of("decoder.conv_out"), -1, nullptr, Act{-1, c.out_channels, RO, RO}, false,
+                       "decoder.conv_norm_out + conv_out", true);
             if (rc) return rc;
-            const float *db = bias_of("decoder.conv_out");
-            if (rc) return rc;
-            ConvArgs a{};
-            a.nseg = 1;
-            a.seg[0].C = C0;
-            a.seg[0].taps = 9;
-            a.seg[0].up = 0;
-            a.Wgt = Wp;
-            a.bias = db;
-            a.H = RO;
-            a.W = RO;
-            a.stride = 1;
-            a.Cout = c.out_channels;
-            a.Ktot = K;
-            a.splitk = 1;
-            a.zeros = h->zeros;
-            const int sy = y.slot;
-            cur_name = S("conv decoder.conv_out K=%d N=%d %dx%d", K, c.out_channels, RO, RO);
-            push(OPC_CONV, 2.0 * 9 * C0 * c.out_channels * RO * RO, [=](RunCtx &r) {
-                ConvArgs cc = a;
-                cc.seg[0].src = hh->P(sy);
-                cc.B = r.B;
-                cc.out = r.out;
-                return launch_conv(hh->dtype(), TILE_128x32, EPI_NCHW32, cc, r.st);
-            });
         }
         materialize();
         return rc;
@@ -1209,7 +1186,14 @@ struct Builder {
             }
         }
         // ---- head ---------------------------------------------------------------------------------
-        {
+        if (use_fused && R >= 16 && C0 <= 512) {
+            // conv_norm_out + SiLU + conv_out in one conv_t32 launch (32-channel tiles, fp32 NCHW output)
+            const GnSpec g = gn_table(x, nullptr, "conv_norm_out");
+            if (rc) return rc;
+            conv_fused({FIn{x, 9, 0, 0}}, {WSeg{&h->hp("conv_out.weight"), C0, 0, C0, 9}}, &g, true, bias_of("conv_out"), -1,
+                       nullptr, Act{-1, c.out_channels, R, R}, false, "conv_norm_out + conv_out", true);
+            if (rc) return rc;
+        } else {
             Act y = scratch(h->s_y, C0, R, R);
             group_norm(x, nullptr, "conv_norm_out", true, y);
             if (rc) return rc;

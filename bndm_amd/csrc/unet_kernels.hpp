@@ -118,13 +118,14 @@ struct FusedArgs {
     const float *temb;
     int temb_bstride, temb_off;
     const void *resid;
-    void *out;           // NHWC 16-bit
+    void *out;           // NHWC 16-bit; fp32 NCHW [B][Cout][H][W] when out_nchw32
+    int out_nchw32;      // 1: network head (Cout <= 32, no residual / statistics / time embedding)
     float *stats;        // [B][tiles_per_sample][Cout][2] or nullptr
     int B, H, W, Cout;
     const void *zeros;   // >= 16 bytes of zeros
     // In-kernel GroupNorm finalisation (gn_p1 != nullptr; `ss` is then ignored): every workgroup turns the per-tile
     // partial sums of its sample into the scale / shift table itself, in its prologue -- no gn_finalize2 launch.
-    // gn_p1 / gn_p2: [B][gn_ns1 / gn_ns2][gn_C1 / ssC - gn_C1][2] (sum, sum of squares); at most 16 slabs each.
+    // gn_p1 / gn_p2: [B][gn_ns1 / gn_ns2][gn_C1 / ssC - gn_C1][2] (sum, sum of squares); at most 32 slabs each.
     const float *gn_p1, *gn_p2, *gn_gamma, *gn_beta;
     int gn_ns1, gn_ns2, gn_C1, gn_HW;
     float gn_eps;
@@ -136,8 +137,9 @@ bool conv_t32_supports(const FusedArgs &a);
 int launch_conv_t32(int dtype, int TH, const FusedArgs &a, hipStream_t st);
 int conv_t32_tiles_per_sample(int TH, int H, int W);
 // w_of(segment, out channel, channel within the segment, tap) -> fp32 weight; result is [n-tile][K-step][128][32]
+// rows: output channels per n-tile (128, or 32 for the head)
 std::vector<float> pack_weights_t32(const FusedSeg *seg, int nseg, int Cout,
-                                    const std::function<float(int, int, int, int)> &w_of);
+                                    const std::function<float(int, int, int, int)> &w_of, int rows = 128);
 // one-launch GroupNorm(+SiLU) for small per-sample tensors (statistics + apply, one block per sample)
 // x1 given as split-K partial sums: element = round16(sum_z part[z] + bias + temb + resid); the rounded value is also
 // stored to raw_out (the tensor splitk_reduce would have produced, bit-identical)
