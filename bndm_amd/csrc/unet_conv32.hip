@@ -689,7 +689,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
         }
         return;
     }
-    // ---- epilogue 1: bias + time embedding -> 16-bit tile in LDS ([BM][128 ch], swizzled) ---------------
+    // ---- epilogue 1: bias + time embedding -> 16-bit tile in LDS ([BM][NCO ch], 16-byte chunks swizzled) ---------------
+    constexpr int CH = NCO / 8;                          // 16-byte chunks per staged pixel row (16 or 8)
+    constexpr int RB = NCO * 2;                          // bytes per staged pixel row
+    auto skey = [](int pl) { return CH == 16 ? (pl & 15) : ((pl >> 1) & 7); };   // conflict-free for the writes and the reads
     char *stg = smem;
     f32x4 addv[TN][4];
 #pragma unroll
@@ -709,16 +712,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
                 v4 ov;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ov[e] = (T)(acc[i][j][4 * g + e] + addv[i][g][e]);
-                *reinterpret_cast<v4 *>(stg + pl * 256 + ((((cl >> 3) ^ (pl & 15)) << 4) | ((cl & 7) * 2))) = ov;
+                *reinterpret_cast<v4 *>(stg + pl * RB + ((((cl >> 3) ^ skey(pl)) << 4) | ((cl & 7) * 2))) = ov;
             }
     }
     __syncthreads();
     life(4);
 
     // ---- epilogue 2: residual (row-coalesced 16-B reads) + full-row stores + per-channel statistics ------
-    constexpr int RPE = NT / 16;                         // pixel rows handled per pass (16)
+    constexpr int RPE = NT / CH;                         // pixel rows handled per pass
     constexpr int NPASS = BM / RPE;
-    const int c16 = tid & 15, prw = tid >> 4;            // 16-byte chunk (8 channels), pixel row slot
+    const int c16 = tid % CH, prw = tid / CH;            // 16-byte chunk (8 channels), pixel row slot
     v8 rres[NPASS];
     if (a.resid) {
 #pragma unroll
@@ -734,7 +737,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
         const int pl = prw + RPE * i;
-        v8 v = *reinterpret_cast<const v8 *>(stg + pl * 256 + ((c16 ^ (pl & 15)) << 4));
+        v8 v = *reinterpret_cast<const v8 *>(stg + pl * RB + ((c16 ^ skey(pl)) << 4));
         if (a.resid) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rres[i][e]);
@@ -749,27 +752,31 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
         }
     }
     if (a.stats) {
-        // the four row slots of a wave (lanes l, l^16, l^32, l^48) in a fixed order, then the four waves through LDS
+        // the row slots of a wave (lanes with equal l % CH) in a fixed order, then the waves through LDS
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
+            if constexpr (CH == 8) {
+                s1[e] += __shfl_xor(s1[e], 8);
+                s2[e] += __shfl_xor(s2[e], 8);
+            }
             s1[e] += __shfl_xor(s1[e], 16);
             s2[e] += __shfl_xor(s2[e], 16);
             s1[e] += __shfl_xor(s1[e], 32);
             s2[e] += __shfl_xor(s2[e], 32);
         }
-        float *red = reinterpret_cast<float *>(smem + BM * 256);           // [4 waves][128][2]
-        if (l < 16) {
+        float *red = reinterpret_cast<float *>(smem + BM * RB);            // [NW waves][NCO][2]
+        if (l < CH) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                red[((w * 128) + c16 * 8 + e) * 2 + 0] = s1[e];
-                red[((w * 128) + c16 * 8 + e) * 2 + 1] = s2[e];
+                red[((w * NCO) + c16 * 8 + e) * 2 + 0] = s1[e];
+                red[((w * NCO) + c16 * 8 + e) * 2 + 1] = s2[e];
             }
         }
         __syncthreads();
-        if (tid < 256) {
+        if (tid < 2 * NCO) {
             float t = 0.f;
 #pragma unroll
-            for (int wv = 0; wv < NW; ++wv) t += red[wv * 256 + tid];
+            for (int wv = 0; wv < NW; ++wv) t += red[wv * 2 * NCO + tid];
             a.stats[((size_t)(b * tps + tin) * a.Cout + n0) * 2 + tid] = t;
         }
     }
@@ -782,7 +789,7 @@ template <int TH, int NW, int NCO = 128> constexpr int t32_smem_bytes() {
     constexpr int NREMW = (NPIECE - (NROUND - 1) * NT + 63) / 64;
     constexpr int PATCH_BYTES = (NROUND - 1) * NT * 16 + NREMW * 1024;
     constexpr int main_bytes = 2 * PATCH_BYTES + 4 * NCO * 64 + T32_SS_BYTES + T32_MAX_CHUNKS * 16 + 512 + 1024;
-    constexpr int epi_bytes = NCO == 128 ? TH * 16 * 256 + NW * 128 * 2 * 4 : 0;
+    constexpr int epi_bytes = NCO >= 64 ? TH * 16 * NCO * 2 + NW * NCO * 2 * 4 : 0;
     return main_bytes > epi_bytes ? main_bytes : epi_bytes;
 }
 
@@ -865,7 +872,8 @@ bool conv_t32_supports(const FusedArgs &a) {
     }
     if (a.ss && 2 * a.ssC * 4 > T32_SS_BYTES) return false;
     return a.nseg >= 1 && a.seg[0].taps == 9 && nchunks <= T32_MAX_CHUNKS && a.W % 16 == 0 &&
-           (a.out_nchw32 ? a.Cout <= 32 && !a.resid && !a.stats && !a.temb : a.Cout % 128 == 0);
+           (a.out_nchw32 ? a.Cout <= 32 && !a.resid && !a.stats && !a.temb
+                         : a.Cout % 128 == 0);
 }
 
 int conv_t32_tiles_per_sample(int TH, int H, int W) { return (H / TH) * (W / 16); }

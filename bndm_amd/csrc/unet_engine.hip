@@ -556,6 +556,7 @@ struct Builder {
         {
             a.Ktot = Ktot;
             a.out_nchw32 = head ? 1 : 0;
+            a.nco = 128;     // (64-channel tiles for the small grids were tried: the doubled patch DMA + normalisation loses)
             a.B = h->cfg.max_batch;
             a.ss = normed ? (const float *)h->zeros : nullptr;
             if (!conv_t32_supports(a)) {

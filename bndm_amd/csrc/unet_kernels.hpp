@@ -120,6 +120,7 @@ struct FusedArgs {
     const void *resid;
     void *out;           // NHWC 16-bit; fp32 NCHW [B][Cout][H][W] when out_nchw32
     int out_nchw32;      // 1: network head (Cout <= 32, no residual / statistics / time embedding)
+    int nco;             // output channels per workgroup tile (128)
     float *stats;        // [B][tiles_per_sample][Cout][2] or nullptr
     int B, H, W, Cout;
     const void *zeros;   // >= 16 bytes of zeros
