@@ -79,6 +79,15 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l = tid & 63;
+    // profiling aid (BNDM_IGEMM_TRACE): block (0, 0) records s_memtime marks of its first 24 K-steps and of its life
+    const bool tracing = EPI != EPI_SPLITK_FUSED && a.counters != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
+    auto xmark = [&](int k) {
+        if (tracing) {
+            const unsigned tm = (unsigned)__builtin_amdgcn_s_memtime();
+            if (l == 0) a.counters[16 * 24 * 5 + w * 4 + k] = tm;
+        }
+    };
+    xmark(0);
 
     // ---- XCD-aware tile id: consecutive tiles (shared halos / shared weights) stay on one XCD -----
     const int nblk = ntm * ntn;
@@ -140,31 +149,50 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
             vmask[i] = vm;
         }
     }
-    const int4 *stab = reinterpret_cast<const int4 *>(a.steps);
-    auto seg_of = [&](int si) {
-        ConvSeg sg = a.seg[0];
-        if (si == 1) sg = a.seg[1];
-        if (si == 2) sg = a.seg[2];
-        if (si == 3) sg = a.seg[3];
-        return sg;
-    };
+    // The step table is read through the constant address space: a uniform load from plain global memory is emitted as
+    // a VECTOR load + readfirstlane, and the s_waitcnt vmcnt(0) in front of that readfirstlane drains every LDS-DMA
+    // stage in flight -- the ring would run one stage deep.  As s_load it only touches lgkmcnt.
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) i32x4 *const_int4_ptr;
+    const const_int4_ptr stab = (const_int4_ptr)a.steps;
+    // segment descriptors live in SGPRs (selected by value): indexing the kernel argument dynamically would put a
+    // scalar load + lgkmcnt(0) in front of every stage
+    static_assert(CONV_MAX_SEG == 4, "segment select below is written out for four segments");
+#define BNDM_SEG_SGPRS(i)                                                                          \
+    const uint32_t sg_lo##i = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)a.seg[i].src);    \
+    const uint32_t sg_hi##i = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)a.seg[i].src >> 32)); \
+    const uint32_t sg_c2##i = __builtin_amdgcn_readfirstlane(a.seg[i].C * 2);
+    BNDM_SEG_SGPRS(0) BNDM_SEG_SGPRS(1) BNDM_SEG_SGPRS(2) BNDM_SEG_SGPRS(3)
+#undef BNDM_SEG_SGPRS
     // the descriptor of the NEXT staged step is fetched while the current one is used, so the scalar load
     // never sits right in front of an lgkmcnt wait
-    int4 dsc = FAST ? stab[min(ks_begin, ksteps - 1)] : int4{0, 0, 0, 0};
-    auto stage_fast = [&](int buf, int ks) {
+    i32x4 dsc = {0, 0, 0, 0};
+    if (FAST) dsc = stab[min(ks_begin, ksteps - 1)];
+    auto stage_fast = [&](int buf, int ks) __attribute__((always_inline)) {
         char *base = smem + buf * STAGE;
         const int kc = min(ks, ksteps - 1);
-        const int4 d = dsc;
+        const i32x4 d = dsc;
         dsc = stab[min(ks + 1, ksteps - 1)];
-        const ConvSeg sg = seg_of(d.x & 0xff);
+        const int si = d.x & 0xff;
+        // scalar selects written as instructions: a C++ select over lambda-captured values is folded into an indexed
+        // load from the closure object, which then keeps the closure AND the whole argument struct in scratch
+        uint32_t blo = sg_lo0, bhi = sg_hi0, C2 = sg_c20;
+#define BNDM_SSEL(k)                                                                                           \
+    asm("s_cmp_eq_u32 %3, " #k "\n\ts_cselect_b32 %0, %4, %0\n\ts_cselect_b32 %1, %5, %1\n\ts_cselect_b32 %2, %6, %2" \
+        : "+s"(blo), "+s"(bhi), "+s"(C2)                                                                      \
+        : "s"(si), "s"(sg_lo##k), "s"(sg_hi##k), "s"(sg_c2##k)                                                \
+        : "scc");
+        BNDM_SSEL(1) BNDM_SSEL(2) BNDM_SSEL(3)
+#undef BNDM_SSEL
         const int tap = (d.x >> 8) & 0xf;
-        const int C2 = sg.C * 2, lead = (Ws + 1) * C2;                   // bytes of one row + one pixel
-        const __amdgpu_buffer_rsrc_t rs = uniform_rsrc((const char *)sg.src - lead, a.B * Hs * Ws * C2 + lead);
+        const int lead = (Ws + 1) * (int)C2;                             // bytes of one row + one pixel
+        const __amdgpu_buffer_rsrc_t rs =
+            uniform_rsrc((const char *)(((uint64_t)bhi << 32) | blo) - lead, a.B * Hs * Ws * (int)C2 + lead);
         const int soff = __builtin_amdgcn_readfirstlane(d.w);            // (tap shift + row + pixel) * C2 + chunk * 128
 #pragma unroll
         for (int i = 0; i < NXP; ++i) {
             const bool ok = (vmask[i] >> tap) & 1;
-            const unsigned voff = ok ? (unsigned)(pbase[i] * C2 + lchunk * 16) : 0x80000000u;
+            const unsigned voff = ok ? (unsigned)(pbase[i] * (int)C2 + lchunk * 16) : 0x80000000u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(base + i * (RPI * 128) + w * 1024), 16, voff, soff, 0, 0);
         }
 #pragma unroll
@@ -172,7 +200,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
             glds16(wsrc[i] + (size_t)kc * wstep, base + X_BYTES + i * (RPI * 128) + w * 1024);
     };
 
-    auto stage = [&](int buf, const KIter &k, int ks) {
+    auto stage = [&](int buf, const KIter &k, int ks) __attribute__((always_inline)) {
         char *base = smem + buf * STAGE;
         const ConvSeg sg = a.seg[k.seg];
         int dy = 0, dx = 0;
@@ -233,8 +261,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
         }
     }
     int cur = 0, nxt = STAGES - 1;
-    // profiling aid (BNDM_IGEMM_TRACE): block (0, 0) records s_memtime marks of its first 24 K-steps
-    const bool tracing = EPI != EPI_SPLITK_FUSED && a.counters != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
+    constexpr bool dephase = WAVES_M * WAVES_N >= 8;
     auto mark = [&](int it, int k) {
         if (tracing && it < 24) {
             const unsigned tm = (unsigned)__builtin_amdgcn_s_memtime();
@@ -251,15 +278,22 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         mark(it, 2);
-        if (issued < nsteps) {
-            if (FAST) {
-                stage_fast(nxt, ks_begin + issued);
-            } else {
-                stage(nxt, kit, ks_begin + issued);
-                if (issued + 1 < nsteps) kiter_next(kit, a);
+        // The two waves of a SIMD are de-phased: the first issues the next stage BEFORE its MFMAs, its partner AFTER
+        // them, so that one wave's MFMAs cover the other's address/issue time (all waves in lock-step would serialise
+        // the 32 KiB of LDS-DMA issue and the MFMA work of every K-step).
+        auto issue_next = [&]() __attribute__((always_inline)) {
+            if (issued < nsteps) {
+                if (FAST) {
+                    stage_fast(nxt, ks_begin + issued);
+                } else {
+                    stage(nxt, kit, ks_begin + issued);
+                    if (issued + 1 < nsteps) kiter_next(kit, a);
+                }
+                ++issued;
             }
-            ++issued;
-        }
+        };
+        const bool late = dephase && w >= (WAVES_M * WAVES_N) / 2;
+        if (!late) issue_next();
         mark(it, 3);
         const char *Xt = smem + cur * STAGE;
         const char *Wt = Xt + X_BYTES;
@@ -282,11 +316,13 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int j = 0; j < TM; ++j) acc[i][j] = TT<T>::mfma(af[s][i], bf[s][j], acc[i][j]);
+        if (late) issue_next();
         mark(it, 4);
         cur = cur + 1 == STAGES ? 0 : cur + 1;
         nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
     }
 
+    xmark(1);
     // ---- epilogue: lane owns pixel (l&31) of each M-tile and channels 8g + 4*kh + {0..3} -----------
     const int HW = 1 << (logW + logH);
 #pragma unroll
@@ -349,6 +385,10 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
         }
     }
 
+    if (tracing) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        xmark(2);
+    }
     if (EPI == EPI_SPLITK_FUSED) {
         // ---- in-launch split-K reduction (agent-scope release / acquire, placement independent) -----------
         // every wave: slab stores retired; then ONE lane publishes with a release fence and takes a ticket
@@ -778,18 +818,22 @@ int launch_conv_cfg2(const ConvArgs &a, hipStream_t st) {
         static bool done = false;
         const int want = getenv("BNDM_IGEMM_TRACE_KSTEPS") ? atoi(getenv("BNDM_IGEMM_TRACE_KSTEPS")) : 144;
         if (!done && ksteps == want) {
-            if (!buf) BNDM_CHECK_HIP(hipMalloc(&buf, 16 * 24 * 5 * sizeof(unsigned)));
-            BNDM_CHECK_HIP(hipMemsetAsync(buf, 0, 16 * 24 * 5 * sizeof(unsigned), st));
+            if (!buf) BNDM_CHECK_HIP(hipMalloc(&buf, (16 * 24 * 5 + 64) * sizeof(unsigned)));
+            BNDM_CHECK_HIP(hipMemsetAsync(buf, 0, (16 * 24 * 5 + 64) * sizeof(unsigned), st));
             ConvArgs t = a;
             t.counters = buf;
             hipLaunchKernelGGL((conv_igemm<T, WM, WN, TM, TN, EPI, STAGES, FAST>), grid, dim3(WM * WN * 64), smem, st, t,
                                ksteps, ilog2(a.W), ilog2(a.H), ntm, ntn);
             BNDM_CHECK_HIP(hipStreamSynchronize(st));
-            unsigned hbuf[16 * 24 * 5];
+            unsigned hbuf[16 * 24 * 5 + 64];
             BNDM_CHECK_HIP(hipMemcpy(hbuf, buf, sizeof(hbuf), hipMemcpyDeviceToHost));
             if (FILE *f = fopen(getenv("BNDM_IGEMM_TRACE"), "w")) {
                 fprintf(f, "# waves %d tile %dx%d splitk %d ksteps %d grid %d M=%d N=%d\n", WM * WN, WM * TM * 32, WN * TN * 32,
                         a.splitk, ksteps, ntm * ntn, a.B * a.H * a.W, a.Cout);
+                for (int w = 0; w < WM * WN; ++w)
+                    fprintf(f, "w%d life: entry %d loop-end %u stores-retired %u (relative to the first K-step mark of wave 0)\n", w,
+                            (int)(hbuf[16 * 24 * 5 + w * 4] - hbuf[0]), hbuf[16 * 24 * 5 + w * 4 + 1] - hbuf[0],
+                            hbuf[16 * 24 * 5 + w * 4 + 2] - hbuf[0]);
                 for (int w = 0; w < WM * WN; ++w)
                     for (int it = 0; it < 24; ++it) {
                         fprintf(f, "w%d s%d", w, it);

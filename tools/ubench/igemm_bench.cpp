@@ -1,0 +1,106 @@
+// Stand-alone timing of single implicit-GEMM launches of libbndm_hip.so on synthetic low-resolution layers, with the
+// weights (and optionally the activations) rotated through more copies than the caches hold ("cold") or kept in place
+// ("hot").  Profiling aid, built by tools/ubench/build.sh; not part of the product.
+#include "../../bndm_amd/csrc/unet_kernels.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+using namespace bndm;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+struct Case { const char *name; int B, H, C1, C2, Cout, taps, splitk, tile; };
+
+static void run(const Case &c, int ncopy_w, int ncopy_a, int pf) {
+    const int M = c.B * c.H * c.H, Ktot = c.taps * (c.C1 + c.C2);
+    const size_t wbytes = (size_t)((c.Cout + 127) / 128 * 128) * Ktot * 2;
+    const size_t a1 = (size_t)M * c.C1 * 2, a2 = (size_t)M * c.C2 * 2;
+    char *W, *A1, *A2 = nullptr; float *part; void *zeros, *dtab;
+    CK(hipMalloc(&W, wbytes * ncopy_w)); CK(hipMemset(W, 0x2c, wbytes * ncopy_w));
+    CK(hipMalloc(&A1, a1 * ncopy_a)); CK(hipMemset(A1, 0x2c, a1 * ncopy_a));
+    if (c.C2) { CK(hipMalloc(&A2, a2 * ncopy_a)); CK(hipMemset(A2, 0x2c, a2 * ncopy_a)); }
+    CK(hipMalloc(&part, (size_t)c.splitk * M * c.Cout * 4));
+    CK(hipMalloc(&zeros, 256)); CK(hipMemset(zeros, 0, 256));
+    ConvArgs a{};
+    a.nseg = c.C2 ? 2 : 1;
+    a.seg[0] = ConvSeg{A1, c.C1, c.taps, 0};
+    if (c.C2) a.seg[1] = ConvSeg{A2, c.C2, c.taps, 0};
+    a.B = c.B; a.H = c.H; a.W = c.H; a.stride = 1; a.Cout = c.Cout; a.Ktot = Ktot; a.zeros = zeros;
+    a.splitk = c.splitk; a.out = part; a.wtiled = 1; a.wmajor = 1;
+    const std::vector<int> tab = build_conv_steps(a.seg, a.nseg, c.H, 1);
+    CK(hipMalloc(&dtab, tab.size() * 4)); CK(hipMemcpy(dtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    a.steps = dtab;
+    const int ntm = (M + conv_tile_bm(c.tile) - 1) / conv_tile_bm(c.tile), ntn = (c.Cout + 127) / 128;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int reps = 48;
+    float best = 1e9f, sum = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        CK(hipEventRecord(e0, 0));
+        for (int r = 0; r < reps; ++r) {
+            ConvArgs q = a;
+            q.Wgt = W + wbytes * (r % ncopy_w);
+            q.seg[0].src = A1 + a1 * (r % ncopy_a);
+            if (c.C2) q.seg[1].src = A2 + a2 * (r % ncopy_a);
+            if (launch_conv(BNDM_DTYPE_F16, c.tile, EPI_F32_ROWS, q, 0)) { printf("launch failed: %s\n", bndm_last_error()); exit(1); }
+        }
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (pass) { best = ms < best ? ms : best; sum += ms; }
+    }
+    const double us = best * 1e3 / reps, fl = 2.0 * M * c.Cout * (double)Ktot;
+    printf("%-28s M=%5d N=%4d K=%5d split=%2d grid=%4d  w-copies=%3d a-copies=%3d pf=%d : %7.2f us/launch (avg %7.2f)  %6.1f TF/s  W %5.2f MB -> %5.2f TB/s\n",
+           c.name, M, c.Cout, Ktot, c.splitk, ntm * ntn * c.splitk, ncopy_w, ncopy_a, pf, us, sum / 3 * 1e3 / reps, fl / us * 1e-6,
+           wbytes / 1e6, wbytes / us * 1e-6);
+    CK(hipFree(W)); CK(hipFree(A1)); if (A2) CK(hipFree(A2)); CK(hipFree(part)); CK(hipFree(zeros)); CK(hipFree(dtab));
+}
+
+__global__ void empty_kernel(int *p) { if (p && threadIdx.x == 12345) p[0] = 1; }
+__global__ void touch_kernel(float *p, int n) {           // one dependent global load -> store per thread
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = p[i] * 1.0001f + 1.f;
+}
+static void floors() {
+    float *buf; CK(hipMalloc(&buf, 64 << 20)); CK(hipMemset(buf, 0, 64 << 20));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int mode = 0; mode < 4; ++mode) {
+        float best = 1e9f;
+        const int reps = 200;
+        for (int pass = 0; pass < 4; ++pass) {
+            CK(hipEventRecord(e0, 0));
+            for (int r = 0; r < reps; ++r) {
+                if (mode == 0) hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, 0, (int *)nullptr);
+                if (mode == 1) hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(512), 0, 0, (int *)nullptr);
+                if (mode == 2) hipLaunchKernelGGL(touch_kernel, dim3(256), dim3(512), 0, 0, buf, 256 * 512);
+                if (mode == 3) hipLaunchKernelGGL(touch_kernel, dim3(8192), dim3(512), 0, 0, buf, 8192 * 512);
+            }
+            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (pass && ms < best) best = ms;
+        }
+        const char *names[] = {"empty 1x64", "empty 256x512", "load+store 256x512 (0.5 MB)", "load+store 8192x512 (16 MB)"};
+        printf("back-to-back %-30s %6.2f us/launch\n", names[mode], best * 1e3 / reps);
+    }
+    CK(hipFree(buf));
+}
+
+int main(int argc, char **argv) {
+    floors();
+    const Case cases[] = {
+        {"4x4 conv 512->512", 64, 4, 512, 0, 512, 9, 8, TILE_128x128},
+        {"4x4 conv 1024->512", 64, 4, 512, 512, 512, 9, 8, TILE_128x128},
+        {"2x2 conv 512->512", 64, 2, 512, 0, 512, 9, 9, TILE_128x128},
+        {"2x2 conv 1024->512", 64, 2, 512, 512, 512, 9, 18, TILE_128x128},
+        {"8x8 conv 256->256", 64, 8, 256, 0, 256, 9, 4, TILE_128x128},
+        {"8x8 conv 512->256", 64, 8, 256, 256, 256, 9, 4, TILE_128x128},
+        {"4x4 1x1 512->1536 (qkv)", 64, 4, 512, 0, 1536, 1, 1, TILE_128x128},
+        {"4x4 1x1 512->512 (to_out)", 64, 4, 512, 0, 512, 1, 1, TILE_128x128},
+    };
+    const int only = argc > 1 ? atoi(argv[1]) : -1;
+    for (int i = 0; i < (int)(sizeof(cases) / sizeof(cases[0])); ++i) {
+        if (only >= 0 && i != only) continue;
+        run(cases[i], 1, 1, 0);      // hot
+        run(cases[i], 48, 1, 0);     // weights cold (48 copies > L2 + MALL), activations hot
+        run(cases[i], 48, 48, 0);    // everything cold
+    }
+    return 0;
+}
