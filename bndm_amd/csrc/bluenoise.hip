@@ -176,46 +176,48 @@ constexpr int SM_NSEG = NPIX / SM_KSEG;          // 32
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+constexpr int SM_NST = 2;                        // LDS stages (deeper rings measured slower: the per-CU miss queue, not the ring, bounds what is in flight)
+constexpr int SM_STAGE = SM_BM * SM_BK * 4 + 32 * SM_BK * 4;     // 16 KiB of L (128 rows x 128 B) + 4 KiB of z (32 cols x 128 B)
+
 template <bool W16>
 __global__ __launch_bounds__(256, 4) void bluenoise_small(const float *__restrict__ L, ZSrc zs, float *__restrict__ part,
                                                           int ncols, int f_begin, int dense) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * (SM_BM * SM_BK * 4 + 32 * SM_BK * 4)];
-    constexpr int L_BYTES = SM_BM * SM_BK * 4;       // 16 KiB: 128 rows x 128 B
-    constexpr int Z_BYTES = 32 * SM_BK * 4;          //  4 KiB:  32 cols x 128 B
-    constexpr int STAGE = L_BYTES + Z_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SM_NST * SM_STAGE];
+    constexpr int L_BYTES = SM_BM * SM_BK * 4;
+    constexpr int STAGE = SM_STAGE;
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l = tid & 63;
 
-    // ---- work units: (128-row panel P, 128-k segment S), S <= P unless dense.  A lower-triangular L has 496
-    // off-diagonal units and 32 diagonal ones (which read 10/16 of a unit: rows above a 32-k slice hold only zeros and
-    // are not fetched); the diagonal units are paired, so that the grid is 512 workgroups = two per CU, every one with
-    // 1 .. 1.25 units of HBM traffic -- the per-CU LDS-DMA rate (~25 GB/s), not the chip's bandwidth, sets the time.
-    int Pu[2], Su[2], nunit = 1;
+    // ---- work unit: (128-row panel P, 128-k segment S), S <= P unless dense.  A lower-triangular L has 32 diagonal
+    // units (which read 10/16 of a unit: rows above a 32-k slice hold only zeros and are not fetched) and 496
+    // off-diagonal ones: 528 workgroups, all resident at once (40 KiB of LDS each).  A workgroup's life is a chain of
+    // memory latencies (two slices requested, ~1.8 us until the first lands, four slices, ~1 us until the slab stores
+    // retire), so every workgroup gets exactly ONE unit: pairing the cheap diagonal units made those workgroups the
+    // critical path of the launch.
+    int P, S;
     {
         const int u = blockIdx.x;
         if (dense) {
-            Pu[0] = 31 - (u >> 5);
-            Su[0] = u & 31;
-        } else if (u < 496) {                      // off-diagonal units, longest panels first: panel P has P of them
-            int rem = u, P = 31;
+            P = 31 - (u >> 5);
+            S = u & 31;
+        } else if (u < 32) {                       // diagonal units
+            P = S = 31 - u;
+        } else {                                   // off-diagonal units, longest panels first: panel P has P of them
+            int rem = u - 32;
+            P = 31;
             while (rem >= P) {
                 rem -= P;
                 --P;
             }
-            Pu[0] = P;
-            Su[0] = rem;
-        } else {                                   // diagonal units (P, P), paired bottom with top
-            Pu[0] = Su[0] = 31 - (u - 496);
-            Pu[1] = Su[1] = u - 496;
-            nunit = 2;
+            S = rem;
         }
-        if (nunit == 1) Pu[1] = Su[1] = 0;
     }
-    for (int un = 0; un < nunit; ++un) {
-    const int P = __builtin_amdgcn_readfirstlane(Pu[un]), S = __builtin_amdgcn_readfirstlane(Su[un]);
+    P = __builtin_amdgcn_readfirstlane(P);
+    S = __builtin_amdgcn_readfirstlane(S);
     const bool diag = !dense && S == P;
     const int i0 = P * SM_BM, kbeg = S * SM_KSEG;
+    constexpr int nslice = SM_KSEG / SM_BK;          // 4
 
     // ---- staging: piece q of a 4-KiB block instruction = row q >> 3, physical chunk q & 7 holds logical chunk
     // (q & 7) ^ ((row >> 1) & 7)
@@ -230,8 +232,8 @@ __global__ __launch_bounds__(256, 4) void bluenoise_small(const float *__restric
     const int fl = zc / zs.C;
     const float *zsrc = z_addr(zs, f_begin + fl, zc - fl * zs.C, 0);
     const int zchunk = 4 * (pchunk ^ ((prow >> 1) & 7));
-    auto stage = [&](int buf, int t) {                               // t: 32-k slice of the segment
-        char *base = smem + buf * STAGE;
+    auto stage = [&](int t) __attribute__((always_inline)) {        // t: 32-k slice of the segment
+        char *base = smem + (t % SM_NST) * STAGE;
 #pragma unroll
         for (int r = 0; r < 4; ++r)                                 // (diagonal unit: rows 32r .. 32r+31 are zero from slice r+1 on:
             glds16(diag && t > r ? lsrc[r] : lsrc[r] + t * SM_BK,   //  re-read slice 0 of the row -- an L2 hit -- instead)
@@ -240,63 +242,69 @@ __global__ __launch_bounds__(256, 4) void bluenoise_small(const float *__restric
         glds16(zsrc + z_row_off(zs.layout, j >> 6) + (zs.layout == BNDM_Z_IMAGE32 ? (j & 31) : (j & 63)),
                base + L_BYTES + w * 1024);
     };
-    // slices of the diagonal unit above this wave's rows hold only zeros of L: skipped (all waves still stage them)
-    const int nslice = SM_KSEG / SM_BK;
-    const int mine = diag ? w + 1 : nslice;
 
-    f32x16 acc32;
-    f32x4v acc16[2][1];
+    f32x16 acc32, acc32b;
+    f32x4v acc16[2][2];              // [k half of the slice][row half]: the two k halves are added when the unit is done
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc32[e] = 0.f;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 1; ++b) acc16[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int e = 0; e < 16; ++e) acc32[e] = acc32b[e] = 0.f;
+    acc16[0][0] = acc16[0][1] = acc16[1][0] = acc16[1][1] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-    stage(0, 0);
-    stage(1, 1);
+#pragma unroll
+    for (int t = 0; t < SM_NST; ++t) stage(t);
     for (int t = 0; t < nslice; ++t) {
         if (t + 1 < nslice) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // slice t landed, slice t+1 may fly
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const float *Lt = reinterpret_cast<const float *>(smem + (t & 1) * STAGE);
-        const float *Zt = reinterpret_cast<const float *>(smem + (t & 1) * STAGE + L_BYTES);
-        if (t < mine) {
+        const float *Lt = reinterpret_cast<const float *>(smem + (t % SM_NST) * STAGE);
+        const float *Zt = reinterpret_cast<const float *>(smem + (t % SM_NST) * STAGE + L_BYTES);
+        // slices of the diagonal unit above this wave's rows hold only zeros of L: skipped (all waves still stage them)
+        if (!diag || t <= w) {
             if constexpr (W16) {
-                // 16x16x4: lane (i = l & 15, kq = l >> 4) holds 4 consecutive k of its row; MFMA e multiplies element e
+                // 16x16x4: lane (i = l & 15, kq = l >> 4) holds 4 consecutive k of its row; MFMA e multiplies element e.
+                // All six fragments are read first; the 16 MFMAs of a slice run as four independent accumulation chains
+                // (k half x row half) instead of two chains of eight dependent instructions.
                 const int i = l & 15, kq = l >> 4;
+                f32x4v zf[2], lf[2][2];
 #pragma unroll
                 for (int b16 = 0; b16 < 2; ++b16) {
                     const int c = 4 * b16 + kq;
-                    const f32x4v zf = *reinterpret_cast<const f32x4v *>(Zt + i * SM_BK + 4 * (c ^ ((i >> 1) & 7)));
+                    zf[b16] = *reinterpret_cast<const f32x4v *>(Zt + i * SM_BK + 4 * (c ^ ((i >> 1) & 7)));
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int row = w * 32 + h * 16 + i;
-                        const f32x4v lf = *reinterpret_cast<const f32x4v *>(Lt + row * SM_BK + 4 * (c ^ ((row >> 1) & 7)));
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            acc16[h][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf[e], lf[e], acc16[h][0], 0, 0, 0);
+                        lf[b16][h] = *reinterpret_cast<const f32x4v *>(Lt + row * SM_BK + 4 * (c ^ ((row >> 1) & 7)));
                     }
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int b16 = 0; b16 < 2; ++b16)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            acc16[b16][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf[b16][e], lf[b16][h][e], acc16[b16][h], 0, 0, 0);
             } else {
                 const int q = l & 31, kh = l >> 5;
                 const int row = w * 32 + q;
 #pragma unroll
-                for (int s = 0; s < SM_BK / 8; ++s) {
-                    const int c = 2 * s + kh;
+                for (int sx = 0; sx < SM_BK / 8; ++sx) {
+                    const int c = 2 * sx + kh;
                     const f32x4v lf = *reinterpret_cast<const f32x4v *>(Lt + row * SM_BK + 4 * (c ^ ((row >> 1) & 7)));
                     const f32x4v zf = *reinterpret_cast<const f32x4v *>(Zt + q * SM_BK + 4 * (c ^ ((q >> 1) & 7)));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc32 = __builtin_amdgcn_mfma_f32_32x32x2f32(zf[e], lf[e], acc32, 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) {                    // two accumulation chains (even / odd k steps)
+                        if (e & 1) acc32b = __builtin_amdgcn_mfma_f32_32x32x2f32(zf[e], lf[e], acc32b, 0, 0, 0);
+                        else acc32 = __builtin_amdgcn_mfma_f32_32x32x2f32(zf[e], lf[e], acc32, 0, 0, 0);
+                    }
                 }
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                            // buffer t & 1 may be overwritten
-        asm volatile("" ::: "memory");
-        if (t + 2 < nslice) stage(t & 1, t + 2);
+        if (t + SM_NST < nslice) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                        // buffer t % SM_NST may be overwritten
+            asm volatile("" ::: "memory");
+            stage(t + SM_NST);
+        }
     }
 
     // ---- D rows = z columns, D cols = L rows: contiguous stores along i ------------------------------------
@@ -308,19 +316,15 @@ __global__ __launch_bounds__(256, 4) void bluenoise_small(const float *__restric
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int col = 4 * kq + e;
-                if (col < ncols) pseg[(size_t)col * NPIX + i0 + w * 32 + h * 16 + i] = acc16[h][0][e];
+                if (col < ncols) pseg[(size_t)col * NPIX + i0 + w * 32 + h * 16 + i] = acc16[0][h][e] + acc16[1][h][e];
             }
     } else {
         const int q = l & 31, kh = l >> 5;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int col = (e & 3) + 8 * (e >> 2) + 4 * kh;
-            if (col < ncols) pseg[(size_t)col * NPIX + i0 + w * 32 + q] = acc32[e];
+            if (col < ncols) pseg[(size_t)col * NPIX + i0 + w * 32 + q] = acc32[e] + acc32b[e];
         }
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                   // (second unit of a diagonal pair re-uses the LDS buffers)
-    asm volatile("" ::: "memory");
     }
 }
 
@@ -445,7 +449,7 @@ extern "C" int bndm_bluenoise(const float *L, int l_dense, const float *z, int z
                      bndm_bluenoise_workspace_bytes(b_count, C, res));
         int rc;
         if (ncols <= 32) {
-            const dim3 grid(l_dense ? 32 * 32 : 512);
+            const dim3 grid(l_dense ? 32 * 32 : 528);
             if (ncols <= 16)
                 hipLaunchKernelGGL(bluenoise_small<true>, grid, dim3(256), 0, st, L, zs, part, ncols, f_begin, l_dense ? 1 : 0);
             else

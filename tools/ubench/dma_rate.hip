@@ -32,6 +32,11 @@ __global__ __launch_bounds__(NW * 64) void rate_kernel(const char *__restrict__ 
             const int o = off + u * 1024 + lane * 16;
             if (MODE == 0) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(wlds + u * 1024), 16, o, 0, 0, 0);
+            } else if (MODE == 3 || MODE == 4) {
+                // 8 rows x 128 B per instruction, rows 16 KiB (MODE 3) or 2 KiB (MODE 4) apart, as a row-panel of a matrix is read
+                const int rstride = MODE == 3 ? 16384 : 2048;
+                const char *p = src + (size_t)(blockIdx.x & 63) * 128 * rstride / 64 + (size_t)((lane >> 3) + 8 * u + 64 * wave) * rstride + (lane & 7) * 16 + (off & (rstride - 1) & ~127);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p, (lds_ptr_t)(wlds + u * 1024), 16, 0, 0);
             } else if (MODE == 1) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + o),
                                                  (lds_ptr_t)(wlds + u * 1024), 16, 0, 0);
@@ -41,7 +46,7 @@ __global__ __launch_bounds__(NW * 64) void rate_kernel(const char *__restrict__ 
             }
         }
         if (MODE != 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        off += 8192;
+        off += (MODE >= 3 ? 128 : 8192);
         if (off >= wave_span) off = 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -179,6 +184,8 @@ int main() {
     ROW(0, "buffer_load_lds_b128")
     ROW(1, "global_load_lds_b128")
     ROW(2, "global_load_dwordx4")
+    ROW(3, "lds_b128 8rows x128B @16K")
+    ROW(4, "lds_b128 8rows x128B @2K")
     run_mix<0, 0>(256, src, win, cyc, sink);
     run_mix<0, 2>(256, src, win, cyc, sink);
     run_mix<0, 4>(256, src, win, cyc, sink);
