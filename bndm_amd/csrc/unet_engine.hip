@@ -129,7 +129,6 @@ struct bndm_unet {
     std::vector<Op> ops;
     int ntemb = 0;                     // total time_emb_proj columns
     void *zeros = nullptr;
-    unsigned *tile_counters = nullptr;   // split-K arrival counters (zeroed once; last arrivers reset them)
     // per-schedule time-embedding table (K10): [cap][ntemb] fp32, [cap] fp32 t, [cap][temb_dim] 16-bit
     float *tp_table = nullptr, *t_steps = nullptr;
     void *act_steps = nullptr;
@@ -702,7 +701,7 @@ struct Builder {
             const int nblk = ceil_div(M, 128) * ceil_div(out.C, 128);
             if (nblk < 192) h->grow(h->s_splitk, (size_t)32 * M * out.C * 4);
         }
-        const bool can_defer = defer && use_defer && use_gn_small && !h->tile_counters && stride == 1 && out.H * out.W <= 64;
+        const bool can_defer = defer && use_defer && use_gn_small && out.H * out.W <= 64;
         push(OPC_CONV, flops, [=](RunCtx &r) mutable {
             ConvArgs c = a;
             for (int i = 0; i < c.nseg; ++i) c.seg[i].src = hh->P(slots[i]);
@@ -718,18 +717,10 @@ struct Builder {
             const int M = r.B * c.H * c.W;
             const ConvPlan pl = plan_conv(M, c.Cout, ksteps, hh->bufs[hh->s_splitk].bytes);
             const int tile = pl.tile, splitk = pl.splitk;
-            const int nblk = ceil_div(M, 128) * ceil_div(c.Cout, 128);
             if (splitk == 1) {
                 c.splitk = 1;
                 c.out = hh->P(so);
                 return launch_conv(hh->dtype(), tile, EPI_NHWC16, c, r.st);
-            }
-            if (tile == TILE_128x128 && hh->tile_counters && nblk <= 4096) {
-                c.splitk = splitk;
-                c.out = hh->P(so);
-                c.part = (float *)hh->P(hh->s_splitk);
-                c.counters = hh->tile_counters;
-                return launch_conv(hh->dtype(), tile, EPI_SPLITK_FUSED, c, r.st);
             }
             ConvArgs p = c;
             p.splitk = splitk;
@@ -973,7 +964,7 @@ struct Builder {
         int K;
         rc = pack_conv_weight(h, {WSeg{&h->hp(name + ".weight"), x.C, 0, x.C, 9}}, x.C, 128, &Wp, &K);
         if (rc) return x;
-        conv({SegIn{x, 9, down ? 0 : 1}}, Wp, K, bias_of(name), -1, nullptr, out, down ? 2 : 1, name);
+        conv({SegIn{x, 9, down ? 0 : 1}}, Wp, K, bias_of(name), -1, nullptr, out, down ? 2 : 1, name, true);
         return out;
     }
 
@@ -1085,12 +1076,6 @@ struct Builder {
             std::vector<char> zz(256, 0);
             if ((rc = upload(h, zz.data(), zz.size(), &z))) return rc;
             h->zeros = z;
-            if (getenv("BNDM_FUSED_SPLITK")) {   // opt-in: in-launch reduction loses to a reduce launch at these slab sizes
-                std::vector<unsigned> cz(4096, 0u);
-                void *cnt;
-                if ((rc = upload(h, cz.data(), cz.size() * 4, &cnt))) return rc;
-                h->tile_counters = (unsigned *)cnt;
-            }
         }
 
         // ---- time embedding MLP (fp32, transposed weights for coalesced reads) ----------------------

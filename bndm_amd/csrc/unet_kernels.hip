@@ -80,7 +80,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l = tid & 63;
     // profiling aid (BNDM_IGEMM_TRACE): block (0, 0) records s_memtime marks of its first 24 K-steps and of its life
-    const bool tracing = EPI != EPI_SPLITK_FUSED && a.counters != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
+    const bool tracing = a.counters != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
     auto xmark = [&](int k) {
         if (tracing) {
             const unsigned tm = (unsigned)__builtin_amdgcn_s_memtime();
@@ -361,11 +361,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
                         for (int e = 0; e < 4; ++e) v[e] += tv[e];
                     }
                 }
-                if (EPI == EPI_SPLITK_FUSED) {
-                    float *o = a.part + (size_t)blockIdx.y * M * a.Cout;
-                    f32x4 ov = {v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4 *>(o + (size_t)m * a.Cout + co) = ov;
-                } else if (EPI == EPI_F32_ROWS) {
+                if (EPI == EPI_F32_ROWS) {
                     float *o = (float *)a.out + (a.splitk > 1 ? (size_t)blockIdx.y * M * a.Cout : 0);
                     f32x4 ov = {v[0], v[1], v[2], v[3]};
                     *reinterpret_cast<f32x4 *>(o + (size_t)m * a.Cout + co) = ov;
@@ -388,50 +384,6 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
     if (tracing) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         xmark(2);
-    }
-    if (EPI == EPI_SPLITK_FUSED) {
-        // ---- in-launch split-K reduction (agent-scope release / acquire, placement independent) -----------
-        // every wave: slab stores retired; then ONE lane publishes with a release fence and takes a ticket
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int *flag = reinterpret_cast<int *>(smem);
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned t = __hip_atomic_fetch_add(a.counters + tix, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flag = (t == (unsigned)a.splitk - 1) ? 1 : 0;
-        }
-        __syncthreads();
-        if (*flag == 0) return;
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(a.counters + tix, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        }
-        __syncthreads();
-        using v4 = typename TT<T>::v4;
-        constexpr int C4 = BN / 4;
-        for (int idx = tid; idx < BM * C4; idx += NT) {
-            const int row = idx / C4, c4 = idx - row * C4;
-            const int m = m0 + row, co = n0 + c4 * 4;
-            if (m >= M || co >= a.Cout) continue;
-            f32x4 sum = *reinterpret_cast<const f32x4 *>(a.part + (size_t)m * a.Cout + co);
-            for (int z = 1; z < a.splitk; ++z)
-                sum += *reinterpret_cast<const f32x4 *>(a.part + ((size_t)z * M + m) * a.Cout + co);
-            if (a.bias) sum += *reinterpret_cast<const f32x4 *>(a.bias + co);
-            if (a.temb) {
-                const int bb = m >> (logW + logH);
-                sum += *reinterpret_cast<const f32x4 *>(a.temb + (size_t)bb * a.temb_bstride + a.temb_off + co);
-            }
-            if (a.resid) {
-                const v4 rv = *reinterpret_cast<const v4 *>((const T *)a.resid + (size_t)m * a.Cout + co);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sum[e] += (float)rv[e];
-            }
-            v4 ov;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ov[e] = (T)sum[e];
-            *reinterpret_cast<v4 *>((T *)a.out + (size_t)m * a.Cout + co) = ov;
-        }
     }
 }
 
@@ -812,7 +764,7 @@ int launch_conv_cfg2(const ConvArgs &a, hipStream_t st) {
         attr = true;
     }
     dim3 grid(ntm * ntn, a.splitk > 1 ? a.splitk : 1);
-    if (EPI != EPI_SPLITK_FUSED && getenv("BNDM_IGEMM_TRACE")) {
+    if (getenv("BNDM_IGEMM_TRACE")) {
         // profiling aid: marks of the first launch whose K-step count equals BNDM_IGEMM_TRACE_KSTEPS are dumped as text
         static unsigned *buf = nullptr;
         static bool done = false;
@@ -879,7 +831,6 @@ int launch_conv_t(int tile, int epi, const ConvArgs &a, hipStream_t st) {
         if (w8 && epi == EPI_F32_ROWS) return launch_conv_cfg<T, 4, 2, 1, 2, EPI_F32_ROWS, 4>(a, st);
         if (epi == EPI_NHWC16) return launch_conv_cfg<T, 2, 2, 2, 2, EPI_NHWC16, 4>(a, st);
         if (epi == EPI_F32_ROWS) return launch_conv_cfg<T, 2, 2, 2, 2, EPI_F32_ROWS, 4>(a, st);
-        if (epi == EPI_SPLITK_FUSED) return launch_conv_cfg<T, 2, 2, 2, 2, EPI_SPLITK_FUSED, 4>(a, st);
     } else if (tile == TILE_128x32) {    // 4 waves, 4-stage ring (80 KB LDS)
         if (epi == EPI_NCHW32) return launch_conv_cfg<T, 4, 1, 1, 1, EPI_NCHW32, 4>(a, st);
         if (epi == EPI_NHWC16) return launch_conv_cfg<T, 4, 1, 1, 1, EPI_NHWC16, 4>(a, st);

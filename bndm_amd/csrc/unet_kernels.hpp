@@ -36,17 +36,14 @@ struct ConvArgs {
     int splitk;          // >1: fp32 partial slabs [splitk][M][Cout] into `out`, no bias
     const void *zeros;   // >= 16 bytes of zeros (source of padding taps)
     const void *steps;   // device copy of build_conv_steps(...) or nullptr (generic addressing)
-    float *part;         // EPI_SPLITK_FUSED: fp32 slabs [splitk][M][Cout]
-    unsigned *counters;  // EPI_SPLITK_FUSED: one arrival counter per output tile (zero before first use)
+    unsigned *counters;  // profiling aid (BNDM_IGEMM_TRACE): s_memtime marks of workgroup (0, 0), else nullptr
     int wtiled;          // 1: Wgt is tile-contiguous and pre-swizzled, [Cout/128][K/64][128 rows][8 slots][8]: slot j of
                          // row r holds k-group j ^ ((r >> 1) & 7) of the step -- one linear 16 KiB read per K-step
     int wmajor;          // 1: consecutive tiles (same XCD, dispatched together) share the WEIGHT panel (same n-tile,
                          // neighbouring m-tiles) -- for layers whose weights outweigh their activations (<= 8x8)
 };
 
-// EPI_SPLITK_FUSED: every K-slice block writes its fp32 slab; the last block to arrive at a tile sums the
-// slabs and applies bias + time embedding + residual -> NHWC 16-bit (no separate reduce launch)
-enum ConvEpilogue { EPI_NHWC16 = 0, EPI_F32_ROWS = 1, EPI_NCHW32 = 2, EPI_SPLITK_FUSED = 3 };
+enum ConvEpilogue { EPI_NHWC16 = 0, EPI_F32_ROWS = 1, EPI_NCHW32 = 2 };
 enum ConvTile { TILE_128x128 = 0, TILE_128x32 = 1, TILE_256x128 = 2 };
 int conv_tile_bm(int tile);
 

@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <string>
+#include <cmath>
 using namespace bndm;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -18,6 +20,15 @@ static void run(const Case &c, int ncopy_w, int ncopy_a, int pf) {
     char *W, *A1, *A2 = nullptr; float *part; void *zeros, *dtab;
     CK(hipMalloc(&W, wbytes * ncopy_w)); CK(hipMemset(W, 0x2c, wbytes * ncopy_w));
     CK(hipMalloc(&A1, a1 * ncopy_a)); CK(hipMemset(A1, 0x2c, a1 * ncopy_a));
+    if (getenv("RANDOM_DATA")) {
+        std::vector<_Float16> hw(wbytes / 2), ha(a1 / 2);
+        unsigned s = 99u;
+        auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+        for (auto &v : hw) v = (_Float16)(rnd() * 0.08f);
+        for (auto &v : ha) v = (_Float16)(rnd() * 2.f);
+        for (int k = 0; k < ncopy_w; ++k) CK(hipMemcpy(W + wbytes * k, hw.data(), wbytes, hipMemcpyHostToDevice));
+        for (int k = 0; k < ncopy_a; ++k) CK(hipMemcpy(A1 + a1 * k, ha.data(), a1, hipMemcpyHostToDevice));
+    }
     if (c.C2) { CK(hipMalloc(&A2, a2 * ncopy_a)); CK(hipMemset(A2, 0x2c, a2 * ncopy_a)); }
     CK(hipMalloc(&part, (size_t)c.splitk * M * c.Cout * 4));
     CK(hipMalloc(&zeros, 256)); CK(hipMemset(zeros, 0, 256));
@@ -34,7 +45,8 @@ static void run(const Case &c, int ncopy_w, int ncopy_a, int pf) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int reps = 48;
     float best = 1e9f, sum = 0;
-    for (int pass = 0; pass < 4; ++pass) {
+    const int npass = getenv("WARM") ? 40 : 4;        // WARM: ~30 ms of launches first (clock ramp), the last three passes count
+    for (int pass = 0; pass < npass; ++pass) {
         CK(hipEventRecord(e0, 0));
         for (int r = 0; r < reps; ++r) {
             ConvArgs q = a;
@@ -45,7 +57,7 @@ static void run(const Case &c, int ncopy_w, int ncopy_a, int pf) {
         }
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        if (pass) { best = ms < best ? ms : best; sum += ms; }
+        if (pass >= npass - 3) { best = ms < best ? ms : best; sum += ms; }
     }
     const double us = best * 1e3 / reps, fl = 2.0 * M * c.Cout * (double)Ktot;
     printf("%-28s M=%5d N=%4d K=%5d split=%2d grid=%4d  w-copies=%3d a-copies=%3d pf=%d : %7.2f us/launch (avg %7.2f)  %6.1f TF/s  W %5.2f MB -> %5.2f TB/s\n",
