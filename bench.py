@@ -108,15 +108,16 @@ def cpu_baseline(seed=0, budget_s=45.0):
     }
 
 
-def pmc_traffic(lib_path, kernel_tag):
+def pmc_traffic(lib_path, kernel_tag, config):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of tools/pmc_traffic.py -- only if
-    they were taken from THIS build of the library (sha256 match); otherwise null (never a stale constant)."""
+    they were taken from THIS build of the library (sha256 match) on THIS workload (the PMC passes run the default
+    configuration, c2); otherwise null (never a stale or foreign constant)."""
     try:
         with open(PMC_TRAFFIC_FILE) as f:
             rec = json.load(f)
         with open(lib_path, "rb") as f:
             sha = hashlib.sha256(f.read()).hexdigest()
-        if rec.get("lib_sha256") == sha and kernel_tag in rec.get("kernels", {}):
+        if rec.get("lib_sha256") == sha and rec.get("config", "c2") == config and kernel_tag in rec.get("kernels", {}):
             return rec["kernels"][kernel_tag]["bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
@@ -297,15 +298,17 @@ def main():
                                    B, 3, C.byref(prof), _lib.current_stream_ptr())
         _lib.check(rc, "bndm_unet_profile")
         from bndm_amd.unet import engine_ops
-        dom = sorted({k for k, _, _ in engine_ops(h) if k == "conv_t32<TH=16>"})
-        kernel_tag = dom[0] if dom else "conv_t32"
+        names = {k for k, _, _ in engine_ops(h)}
+        # the engine marks the 256-pixel-tile launches as dominant; batches too small for them run 128-pixel tiles only
+        kernel_tag = "conv_t32<TH=16>" if "conv_t32<TH=16>" in names else "conv_t32<TH=8>"
+        tile_txt = "256-pixel" if kernel_tag.endswith("16>") else "128-pixel"
         achieved = prof.dom_flops / (prof.ms_dom * 1e-3) / 1e12 if prof.ms_dom > 0 else 0.0
         conv_all = prof.conv_flops / (prof.ms_conv * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": f"{kernel_tag} (GroupNorm+SiLU fused 3x3 conv, 256-pixel x 128-channel tiles, two workgroups per CU)",
+        roof = {"bound": "mfma", "kernel": f"{kernel_tag} (GroupNorm+SiLU fused 3x3 conv, {tile_txt} x 128-channel tiles, two workgroups per CU)",
                 "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F16_TFLOPS, 4),
                 # HBM bytes per launch: rocprofv3 PMC passes of this very build (tools/pmc_traffic.py), else null
-                "traffic": pmc_traffic(_lib.LIB_PATH, kernel_tag),
+                "traffic": pmc_traffic(_lib.LIB_PATH, kernel_tag, args.config),
                 "launches_per_forward": prof.dom_launches,
                 "avg_launch_us": round(prof.ms_dom / max(prof.dom_launches, 1) * 1e3, 2),
                 "algorithmic_flop_per_launch": prof.dom_flops / max(prof.dom_launches, 1),

@@ -1496,6 +1496,14 @@ extern "C" int bndm_unet_finalize(bndm_unet *h) {
     if (const char *e = getenv("BNDM_FUSED_MAX")) b.fused_max = atoi(e);
     int rc = h->kind == 1 ? b.build_vae() : b.build();
     if (rc) return rc;
+    {
+        // the roofline figure follows the 256-pixel-tile launches; a handle too small for any of them (max_batch 8 at
+        // 64 px) reports its 128-pixel-tile launches instead
+        bool any = false;
+        for (const Op &o : h->ops) any = any || o.dominant;
+        if (!any)
+            for (Op &o : h->ops) o.dominant = o.kernel == "conv_t32<TH=8>";
+    }
     for (Buf &bf : h->bufs) {
         BNDM_CHECK_HIP(hipMalloc(&bf.ptr, bf.bytes ? bf.bytes : 16));
     }

@@ -171,7 +171,7 @@ typedef struct bndm_unet_profile_t {
     int   conv_launches;
     double conv_flops;     /* algorithmic 2*MAC of those launches                          */
     int   launches;        /* all kernel launches of one forward                           */
-    /* the single dominant kernel (conv_fused with 256-pixel tiles): the roofline line of bench.py */
+    /* the single dominant kernel (conv_t32 with 256-pixel tiles): the roofline line of bench.py */
     float  ms_dom;         /* sum of its launch durations in one forward                   */
     int    dom_launches;
     double dom_flops;      /* algorithmic 2*MAC of those launches                          */

@@ -152,7 +152,7 @@ def test_iadb_scheduler_step_matches_oracle():
 
 def test_vae_full_layout_at_64x64_latent_matches_oracle():
     """The real decode of the latent path: sd-vae-ft-mse layout, 64x64 latent -> 512x512 image, B=1
-    (latent_iadb_bn_diffusers.py:185-191,531-533): 4096-token one-head attention, conv_tap9 up to 512^2."""
+    (latent_iadb_bn_diffusers.py:185-191,531-533): 4096-token one-head attention, conv_t32 up to 512^2."""
     from oracle import vae_oracle as V
     from bndm_amd.vae import AutoencoderKL, vae_decode
     torch.set_num_threads(32)

@@ -47,6 +47,7 @@ def main():
     fetch, nf = one_pass("FETCH_SIZE", extra)
     write, nw = one_pass("WRITE_SIZE", extra)
     out = {"lib_sha256": hashlib.sha256(open(LIB, "rb").read()).hexdigest(), "command": "bench.py --profile-only " + " ".join(extra),
+           "config": (extra[extra.index("--config") + 1] if "--config" in extra else "c2"),
            "formula": "2 * FETCH_SIZE(KiB) * 1024 + WRITE_SIZE(KiB) * 1024 per launch", "kernels": {}}
     for fam in sorted(fetch):
         if nf[fam] and nw.get(fam):
