@@ -71,10 +71,6 @@ struct Chunk {
 // ABL: profiling switches (results are wrong when non-zero): 1 no MFMA, 2 no weight DMA, 4 no fragment reads,
 // 8 no in-loop patch DMA / normalisation, 16 no in-loop normalisation (DMA kept), 64 record s_memtime marks of
 // block 0 / chunk 1 into dbg[wave][tap][6]
-// stagger: workgroups 256..511 -- the second resident workgroup of every CU in the first dispatch round, as the
-// dispatcher is observed to fill the CUs (a speed assumption only) -- start `stagger` shader cycles late, so that the two
-// workgroups of a CU run out of phase: one's prologue / epilogue (HBM-bound, launch-wide bursts if everybody is in
-// step) falls into the other's MFMA time.  Later workgroups inherit the offset from the slot they take over.
 // NW: waves per workgroup.  4: one wave per SIMD and workgroup, 64 x 128 wave tiles, two workgroups per CU -- for grids
 // of at least two workgroups per CU.  8: 4(M) x 2(N) waves of 64 x 64, two waves per SIMD from ONE workgroup -- for
 // the smaller grids (32x32 and 16x16 layers at batch 64), where a CU would otherwise host a single 4-wave workgroup.
@@ -83,7 +79,7 @@ struct Chunk {
 // written as the caller's fp32 NCHW tensor; the loop is then bound by the one read + normalisation of the input.
 template <typename T, int TH, int ABL, int NW, int NCO>
 __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const int tiles_x, const int tps, const int ntn,
-                                                   const int nsteps_w, const int stagger, unsigned *__restrict__ dbg) {
+                                                   const int nsteps_w, unsigned *__restrict__ dbg) {
     using v8 = typename TT<T>::v8;
     using v4 = typename TT<T>::v4;
     using v2 = typename TT<T>::v2;
@@ -119,10 +115,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
         }
     };
     life(0);
-    if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)stagger) __builtin_amdgcn_s_sleep(64);
-    }
 
     // ---- tile id (XCD-aware: neighbouring tiles of a sample share halos and weights) ---------------
     int tix;
@@ -814,16 +806,13 @@ int launch_t32_t(const FusedArgs &a, hipStream_t st) {
     int nsteps = 0;
     for (int i = 0; i < a.nseg; ++i) nsteps += a.seg[i].taps * (a.seg[i].C / 32);
     dim3 grid(a.B * tps * ntn);
-    // half a workgroup's MFMA time (16 MFMAs of 32 cycles per K-step and wave; twice that while two workgroups share)
-    static const int stagger_pct = getenv("BNDM_T32_STAGGER") ? atoi(getenv("BNDM_T32_STAGGER")) : 50;
-    const int stagger = NW == 4 && grid.x > 256 ? (int)((long long)nsteps * 1024 * (TH / 8) / 2 * stagger_pct / 100) : 0;
     unsigned *dbg = nullptr;
     if constexpr ((ABL & 64) != 0) {
         static unsigned *buf = nullptr;
         if (!buf) BNDM_CHECK_HIP(hipMalloc(&buf, (4 * 9 * 6 + 32) * sizeof(unsigned)));
         dbg = buf;
     }
-    hipLaunchKernelGGL((conv_t32<T, TH, ABL, NW, NCO>), grid, dim3(NW * 64), smem, st, a, tiles_x, tps, ntn, nsteps, stagger, dbg);
+    hipLaunchKernelGGL((conv_t32<T, TH, ABL, NW, NCO>), grid, dim3(NW * 64), smem, st, a, tiles_x, tps, ntn, nsteps, dbg);
     if constexpr ((ABL & 64) != 0) {
         // profiling aid: dump the marks of 8-chunk launches (the K = 2304 layers) as text
         int n9 = 0;

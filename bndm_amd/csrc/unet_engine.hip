@@ -1603,30 +1603,6 @@ extern "C" int bndm_unet_profile(bndm_unet *h, const float *sample, const float 
     float ms = 0;
     BNDM_CHECK_HIP(hipEventElapsedTime(&ms, t0, t1));
     prof->ms_total = ms / iters;
-    if (getenv("BNDM_PROFILE_GRAPH")) {
-        // experiment: the same forward replayed from a captured hipGraph
-        hipStream_t cs;
-        BNDM_CHECK_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        BNDM_CHECK_HIP(hipStreamSynchronize(st));
-        RunCtx rg{B, cs, sample, nullptr, timesteps, out};
-        hipGraph_t g;
-        hipGraphExec_t ge;
-        BNDM_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-        if ((rc = run_forward(h, rg))) return rc;
-        BNDM_CHECK_HIP(hipStreamEndCapture(cs, &g));
-        BNDM_CHECK_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        BNDM_CHECK_HIP(hipGraphLaunch(ge, cs));
-        BNDM_CHECK_HIP(hipEventRecord(t0, cs));
-        for (int i = 0; i < iters; ++i) BNDM_CHECK_HIP(hipGraphLaunch(ge, cs));
-        BNDM_CHECK_HIP(hipEventRecord(t1, cs));
-        BNDM_CHECK_HIP(hipEventSynchronize(t1));
-        float gms = 0;
-        BNDM_CHECK_HIP(hipEventElapsedTime(&gms, t0, t1));
-        fprintf(stderr, "[bndm] forward: stream launches %.3f ms, hipGraph replay %.3f ms\n", ms / iters, gms / iters);
-        (void)hipGraphExecDestroy(ge);
-        (void)hipGraphDestroy(g);
-        (void)hipStreamDestroy(cs);
-    }
     // (2) per-op events, accumulated by class
     double conv_ms = 0, conv_flops = 0;
     int conv_launches = 0;

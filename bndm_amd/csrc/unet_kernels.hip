@@ -822,11 +822,6 @@ int launch_conv_t(int tile, int epi, const ConvArgs &a, hipStream_t st) {
         if (epi == EPI_F32_ROWS) return launch_conv_cfg<T, 4, 2, 2, 2, EPI_F32_ROWS, 3>(a, st);
     } else if (tile == TILE_128x128) {   // 4-stage ring (128 KB LDS); 8 waves (32x64 wave tiles) or 4 (64x64)
         static const int w8 = getenv("BNDM_IGEMM_W8") ? atoi(getenv("BNDM_IGEMM_W8")) : 1;
-        static const int stg = getenv("BNDM_IGEMM_STAGES") ? atoi(getenv("BNDM_IGEMM_STAGES")) : 4;     // experiment
-        if (w8 && stg == 2 && epi == EPI_NHWC16) return launch_conv_cfg<T, 4, 2, 1, 2, EPI_NHWC16, 2>(a, st);
-        if (w8 && stg == 2 && epi == EPI_F32_ROWS) return launch_conv_cfg<T, 4, 2, 1, 2, EPI_F32_ROWS, 2>(a, st);
-        if (w8 && stg == 3 && epi == EPI_NHWC16) return launch_conv_cfg<T, 4, 2, 1, 2, EPI_NHWC16, 3>(a, st);
-        if (w8 && stg == 3 && epi == EPI_F32_ROWS) return launch_conv_cfg<T, 4, 2, 1, 2, EPI_F32_ROWS, 3>(a, st);
         if (w8 && epi == EPI_NHWC16) return launch_conv_cfg<T, 4, 2, 1, 2, EPI_NHWC16, 4>(a, st);
         if (w8 && epi == EPI_F32_ROWS) return launch_conv_cfg<T, 4, 2, 1, 2, EPI_F32_ROWS, 4>(a, st);
         if (epi == EPI_NHWC16) return launch_conv_cfg<T, 2, 2, 2, 2, EPI_NHWC16, 4>(a, st);

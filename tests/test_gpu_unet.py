@@ -62,6 +62,9 @@ def test_batch_independence_and_ragged_batch():
     full = m(x, t, return_dict=False)[0]
     one = m(x[3:4].contiguous(), t[3:4], return_dict=False)[0]
     assert _rel(one.cpu(), full[3:4].cpu()) <= 1e-3
+    # odd batch (row tails of every 128-row tile, ragged split-K slabs) against the oracle
+    ref = U.forward(sd, cfg, x.cpu(), t.cpu())
+    assert _rel(full.cpu(), ref) <= 2e-3
 
 
 def test_state_dict_roundtrip_and_errors(tmp_path):
