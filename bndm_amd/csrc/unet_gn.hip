@@ -62,6 +62,8 @@ __global__ __launch_bounds__(128) void gn_finalize2_kernel(const float *__restri
 // GroupNorm(32) (+SiLU) of cat(x1, x2) for the low-resolution layers (a sample's tensor is at most
 // ~100 KB and stays in L2): statistics and application in ONE launch.  Groups are independent, so a
 // block owns 4 groups (C/8 channels) of one sample: grid (8, B).
+constexpr int GN_SMALL_KEEP = 4;      // rows of its 8-channel chunk a thread keeps in registers between the two passes
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_small_kernel(const T *__restrict__ x1, int C1, const T *__restrict__ x2,
                                                        int C2, int HW, int groups, float eps,
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const T *__restrict__ x1,
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    v8 keep[GN_SMALL_KEEP];
     if (prow < RP) {
         f32x4 add0 = {0.f, 0.f, 0.f, 0.f}, add1 = {0.f, 0.f, 0.f, 0.f};
         if (from_slabs) {
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const T *__restrict__ x1,
                 add1 = *reinterpret_cast<const f32x4 *>(sl.bias + c0 + 4);
             }
         }
-        for (int p = prow; p < HW; p += RP) {
+        auto load_row = [&](int p) __attribute__((always_inline)) {
             v8 v;
             if (from_slabs) {
                 // same operation order as splitk_reduce_kernel: slabs in z order, + bias, + temb, + resid, round
@@ -144,7 +147,15 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const T *__restrict__ x1,
                 s1[e] += f;
                 s2[e] = fmaf(f, f, s2[e]);
             }
+            return v;
+        };
+        // a thread owns at most HW / RP rows (<= 4 for C <= 1024): they stay in registers for the second pass
+#pragma unroll
+        for (int k = 0; k < GN_SMALL_KEEP; ++k) {
+            const int p = prow + k * RP;
+            if (p < HW) keep[k] = load_row(p);
         }
+        for (int p = prow + GN_SMALL_KEEP * RP; p < HW; p += RP) (void)load_row(p);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             red[((size_t)prow * Cb + cl + e) * 2 + 0] = s1[e];
@@ -174,9 +185,8 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const T *__restrict__ x1,
         ss[Cb + c] = beta[sub * Cb + c] - (float)mean * sc;
     }
     __syncthreads();
-    if (prow < RP)
-        for (int p = prow; p < HW; p += RP) {
-            const v8 v = *reinterpret_cast<const v8 *>(src + (size_t)p * Cs);
+    if (prow < RP) {
+        auto apply_row = [&](int p, const v8 &v) __attribute__((always_inline)) {
             v8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -185,7 +195,15 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const T *__restrict__ x1,
                 o[e] = (T)f;
             }
             *reinterpret_cast<v8 *>(out + ((size_t)b * HW + p) * C + c0) = o;
+        };
+#pragma unroll
+        for (int k = 0; k < GN_SMALL_KEEP; ++k) {
+            const int p = prow + k * RP;
+            if (p < HW) apply_row(p, keep[k]);
         }
+        for (int p = prow + GN_SMALL_KEEP * RP; p < HW; p += RP)
+            apply_row(p, *reinterpret_cast<const v8 *>(src + (size_t)p * Cs));
+    }
 }
 
 }  // namespace

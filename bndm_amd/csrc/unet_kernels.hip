@@ -248,10 +248,18 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_igemm(const ConvAr
     KIter kit;
     if (!FAST) kiter_init(kit, a, ks_begin);
     int issued = 0;
+    // the descriptors of the prologue's stages (and of the first in-loop stage) are fetched together: one scalar-load
+    // latency instead of one per stage
+    i32x4 dpre[STAGES];
+    if (FAST) {
+#pragma unroll
+        for (int p = 0; p < STAGES; ++p) dpre[p] = stab[min(ks_begin + p, ksteps - 1)];
+    }
 #pragma unroll
     for (int p = 0; p < STAGES - 1; ++p) {
         if (issued < nsteps) {
             if (FAST) {
+                dsc = dpre[p];
                 stage_fast(p, ks_begin + issued);
             } else {
                 stage(p, kit, ks_begin + issued);
