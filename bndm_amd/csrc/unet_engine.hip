@@ -14,7 +14,9 @@
 #include <cmath>
 #include <cstring>
 #include <functional>
+#include <list>
 #include <map>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -78,9 +80,23 @@ static ConvPlan plan_conv(int M, int Cout, int ksteps, size_t splitk_bytes) {
     return ConvPlan{tile, splitk};
 }
 
+// What the conv_s launch that produces a <= 8x8 tensor writes besides the raw tensor: one GroupNorm(+SiLU) normalised copy
+// per consuming GroupNorm.  Consumers are built after their producer, so they append to this record and the producer's
+// launch closure reads it at run time.
+struct TailOut {
+    struct Req {
+        int slot;
+        const float *gamma, *beta;
+        int gs, silu;
+    };
+    std::vector<Req> reqs;
+    bool raw = true;     // the raw 16-bit tensor is written (false: every consumer reads a normalised copy)
+};
+
 struct Act {       // NHWC 16-bit activation living in buffer slot `slot`
     int slot;
     int C, H, W;
+    std::shared_ptr<TailOut> to;   // produced by conv_s (unet_tail.hip)
 };
 
 struct RunCtx {
@@ -382,7 +398,7 @@ struct Builder {
         static const std::pair<const char *, const char *> fam[] = {
             {"cnvF", "conv_t32"}, {"conv", "conv_igemm"}, {"gnst", "gn_stats"}, {"gnfn", "gn_finalize2"},
             {"gnsm", "gn_small"}, {"gnap", "gn_apply"}, {"rdce", "splitk_reduce"}, {"attn", "attention"},
-            {"temb", "temb_mlp"}, {"post", "pointwise_f32"}, {"deco", "conv_in"}};
+            {"temb", "temb_mlp"}, {"post", "pointwise_f32"}, {"deco", "conv_in"}, {"cnvS", "conv_s"}};
         Op &op = h->ops.back();
         op.kernel = cur_name.substr(0, cur_name.find(' '));
         for (const auto &f : fam)
@@ -742,6 +758,221 @@ struct Builder {
         }
     }
 
+    // ------------------------------------------------------------------------------------------------
+    // <= 8x8 levels: conv_s (unet_tail.hip), one launch per convolution
+    // ------------------------------------------------------------------------------------------------
+    bool use_tail = true;
+    std::vector<std::function<int()>> post_alloc;        // run by finalize once the activation buffers exist
+    bool tail_ok(int H, int W) const {
+        return use_tail && h->kind == 0 && H == W && (H == 8 || H == 4 || H == 2);
+    }
+    struct TSrc {
+        Act a;
+        int kind;                          // TailSegKind
+        const std::vector<float> *w;       // OIHW weight the source multiplies
+        int cin_total, c_begin;            // its input-channel range inside that weight
+    };
+    // GroupNorm(32) over Ctot channels, the part that covers x (channels [off, off + x.C)): written by x's producer when
+    // its groups are whole 8 / 16 / 32-channel blocks of x
+    bool norm_fits(const Act &x, int off, int Ctot) const {
+        const int gs = Ctot / 32;
+        return x.to && Ctot % 32 == 0 && (gs == 8 || gs == 16 || gs == 32) && off % gs == 0 && x.C % gs == 0 &&
+               x.to->reqs.size() < 3;
+    }
+    Act request_norm(const Act &x, const std::string &pname, int off, int Ctot, bool silu) {
+        const std::vector<float> &g = h->hp(pname + ".weight"), &b = h->hp(pname + ".bias");
+        const std::vector<float> gs_(g.begin() + off, g.begin() + off + x.C), bs_(b.begin() + off, b.begin() + off + x.C);
+        const float *gd = nullptr, *bd = nullptr;
+        if ((rc = upload_f32(h, gs_, &gd)) || (rc = upload_f32(h, bs_, &bd))) return x;
+        Act n = new_act(x.C, x.H, x.W);
+        x.to->reqs.push_back(TailOut::Req{n.slot, gd, bd, Ctot / 32, silu ? 1 : 0});
+        return n;
+    }
+    // normalised inputs of a convolution over GroupNorm(cat(x1, x2)): the producers' copies, or one gn_small launch when
+    // the groups straddle the tensors (e.g. 512 + 256 channels: groups of 24)
+    std::vector<TSrc> normed_sources(const Act &x1, const Act *x2, const std::string &pname, bool silu, int kind,
+                                     const std::vector<float> *w) {
+        const int C1 = x1.C, C2 = x2 ? x2->C : 0, C = C1 + C2;
+        std::vector<TSrc> out;
+        if (norm_fits(x1, 0, C) && (!x2 || norm_fits(*x2, C1, C))) {
+            out.push_back(TSrc{request_norm(x1, pname, 0, C, silu), kind, w, C, 0});
+            if (x2 && !rc) out.push_back(TSrc{request_norm(*x2, pname, C1, C, silu), kind, w, C, C1});
+            return out;
+        }
+        bndm_unet *hh = h;
+        Act y = new_act(C, x1.H, x1.W);
+        const float *gamma, *beta;
+        if ((rc = upload_f32(h, h->hp(pname + ".weight"), &gamma)) || (rc = upload_f32(h, h->hp(pname + ".bias"), &beta)))
+            return out;
+        if (x1.to) x1.to->raw = true;
+        if (x2 && x2->to) x2->to->raw = true;
+        const int s1 = x1.slot, s2 = x2 ? x2->slot : -1, so = y.slot, HW = x1.H * x1.W;
+        const float eps_ = gn_eps;
+        cur_name = S("gnsm %-44s C=%-4d %dx%d", pname.c_str(), C, x1.H, x1.W);
+        push(OPC_OTHER, 0, [=](RunCtx &r) {
+            return launch_gn_small(hh->dtype(), hh->P(s1), C1, s2 >= 0 ? hh->P(s2) : nullptr, C2, r.B, HW, GROUPS, eps_,
+                                   gamma, beta, silu ? 1 : 0, hh->P(so), r.st, nullptr);
+        });
+        out.push_back(TSrc{y, kind, w, C, 0});
+        return out;
+    }
+    // one conv_s launch: out[H x W x Cout] = sum over sources (+ bias / time embedding row, + residual); qkv: the q|k|v
+    // projection (rows [Wq; Wk; Wv]) + attention of C / 8 heads -> out is the attention output (before to_out)
+    Act conv_tail(const std::vector<TSrc> &srcs, int Cout, int H, int W, const float *bias, int temb_off, const Act *resid,
+                  const std::string &label, bool qkv = false) {
+        bndm_unet *hh = h;
+        const int HW = H * W, NB = qkv ? 3 : 1, D = tail_ring_depth(NB), rows = qkv ? 3 * Cout : Cout;
+        if (Cout % 32 || (int)srcs.size() > 4) {
+            set_error("conv_s cannot run %s (Cout=%d, %d sources)", label.c_str(), Cout, (int)srcs.size());
+            rc = BNDM_E_ARG;
+            return srcs[0].a;
+        }
+        const int ntn = Cout / 32;
+        int TM = 64;
+        if (!qkv && HW == 64 && (long long)h->cfg.max_batch * HW / 128 * ntn >= 192) TM = 128;
+        std::vector<TailSeg> segs;
+        double mac = 0;
+        for (const TSrc &t : srcs) {
+            if (t.a.C % 32) {
+                set_error("conv_s: %d input channels in %s", t.a.C, label.c_str());
+                rc = BNDM_E_ARG;
+                return srcs[0].a;
+            }
+            segs.push_back(TailSeg{t.kind, t.a.C});
+            mac += (double)(t.kind == TAIL_SEG_1x1 ? 1 : 9) * t.a.C;
+        }
+        const TailPlan plan = build_tail_plan(
+            segs, rows, NB, D,
+            [&](int si, int row, int c, int tap) {
+                const TSrc &t = srcs[si];
+                const int taps = t.kind == TAIL_SEG_1x1 ? 1 : 9;
+                return (*t.w)[((size_t)row * t.cin_total + t.c_begin + c) * taps + tap];
+            },
+            [&](int nt, int nb, int n) { return qkv ? nb * Cout + nt * 32 + n : nt * 32 + n; });
+        const void *dW = nullptr;
+        void *dDesc = nullptr, *dRounds = nullptr;
+        if ((rc = upload_16(h, plan.wgt, &dW))) return srcs[0].a;
+        if ((rc = upload(h, plan.desc.data(), plan.desc.size() * 4, &dDesc))) return srcs[0].a;
+        std::vector<TailRound> rt(plan.nrounds);
+        if ((rc = upload(h, rt.data(), rt.size() * sizeof(TailRound), &dRounds))) return srcs[0].a;
+        {
+            std::vector<int> slots;
+            for (const TSrc &t : srcs) slots.push_back(t.a.slot);
+            const std::vector<TailPlanRound> pr = plan.rounds;
+            std::vector<int> cs;
+            for (const TSrc &t : srcs) cs.push_back(t.a.C);
+            post_alloc.push_back([=]() {
+                std::vector<TailRound> tab(pr.size());
+                for (size_t i = 0; i < pr.size(); ++i) {
+                    tab[i].src = hh->P(slots[pr[i].seg]);
+                    tab[i].row_bytes = cs[pr[i].seg] * 2;
+                    tab[i].cbyte = pr[i].c0 * 2;
+                    tab[i].mode = pr[i].mode;
+                    tab[i].phase = pr[i].phase;
+                    tab[i].nsub = pr[i].nsub;
+                    tab[i].pad = 0;
+                }
+                BNDM_CHECK_HIP(hipMemcpy(dRounds, tab.data(), tab.size() * sizeof(TailRound), hipMemcpyHostToDevice));
+                return 0;
+            });
+        }
+        Act out = new_act(Cout, H, W);
+        if (!qkv) out.to = std::make_shared<TailOut>();
+        for (const TSrc &t : srcs)
+            if (t.a.to && t.kind != TAIL_SEG_3x3 && t.kind != TAIL_SEG_1x1) t.a.to->raw = true;   // resampling reads the raw tensor
+        if (resid && resid->to) resid->to->raw = true;
+        TailArgs a{};
+        a.wgt = dW;
+        a.desc = (const uint32_t *)dDesc;
+        a.rounds = (const TailRound *)dRounds;
+        a.nrounds = plan.nrounds;
+        a.maxsteps = plan.maxsteps;
+        a.tile_bytes = (long long)plan.tile_elems * 2;
+        a.wave_bytes = (int)(plan.wave_elems * 2);
+        a.hwlog = 31 - __builtin_clz(HW);
+        a.wlog = 31 - __builtin_clz(W);
+        a.Cout = Cout;
+        a.ntn = ntn;
+        a.bias = bias;
+        a.temb_off = temb_off >= 0 ? temb_off : 0;
+        a.eps = gn_eps;
+        a.epi = qkv ? TAIL_EPI_ATTN : TAIL_EPI_CONV;
+        const int rs = resid ? resid->slot : -1, so = out.slot;
+        const std::shared_ptr<TailOut> to = out.to;
+        cur_name = S("cnvS %-44s K=%-5d N=%-4d %dx%d", label.c_str(), (int)mac, rows, H, W);
+        const size_t op_index = h->ops.size();
+        push(OPC_CONV, 2.0 * mac * rows * HW + (qkv ? 4.0 * HW * HW * Cout : 0.0), [=](RunCtx &r) {
+            TailArgs c = a;
+            c.B = r.B;
+            c.temb = temb_off >= 0 ? (r.tp_row ? r.tp_row : (const float *)hh->P(hh->s_tp)) : nullptr;
+            c.temb_bstride = r.tp_row ? 0 : hh->ntemb;
+            c.resid = rs >= 0 ? hh->P(rs) : nullptr;
+            if (qkv) {
+                c.attn_out = hh->P(so);
+            } else {
+                c.raw_out = to->raw ? hh->P(so) : nullptr;
+                c.nreq = (int)to->reqs.size();
+                for (int i = 0; i < c.nreq; ++i)
+                    c.req[i] = TailNorm{hh->P(to->reqs[i].slot), to->reqs[i].gamma, to->reqs[i].beta, to->reqs[i].gs,
+                                        to->reqs[i].silu};
+            }
+            return launch_conv_tail(hh->dtype(), TM, NB, c, r.st);
+        });
+        h->ops[op_index].kernel = qkv ? "conv_s<qkv+attention>" : S("conv_s<TM=%d>", TM);
+        h->ops[op_index].bytes_fixed = 2.0 * mac * rows;
+        return out;
+    }
+
+    Act resnet_tail(const Act &x1, const Act *x2, int Cout, const std::string &name, int temb_off) {
+        const int C1 = x1.C, C2 = x2 ? x2->C : 0, Cin = C1 + C2, H = x1.H, W = x1.W;
+        const std::vector<TSrc> s1 =
+            normed_sources(x1, x2, name + ".norm1", true, TAIL_SEG_3x3, &h->hp(name + ".conv1.weight"));
+        if (rc) return x1;
+        const float *bias1 = has_temb ? nullptr : bias_of(name + ".conv1");
+        Act h1 = conv_tail(s1, Cout, H, W, bias1, temb_off, nullptr, name + ".conv1");
+        if (rc) return x1;
+        const bool h1_local = norm_fits(h1, 0, Cout);
+        std::vector<TSrc> s2 = normed_sources(h1, nullptr, name + ".norm2", true, TAIL_SEG_3x3, &h->hp(name + ".conv2.weight"));
+        if (rc) return x1;
+        if (h1_local) h1.to->raw = false;                 // conv2 reads the normalised copy only
+        const float *b2;
+        if (Cin != Cout) {
+            const std::string sc = name + ".conv_shortcut";
+            s2.push_back(TSrc{x1, TAIL_SEG_1x1, &h->hp(sc + ".weight"), Cin, 0});
+            if (x2) s2.push_back(TSrc{*x2, TAIL_SEG_1x1, &h->hp(sc + ".weight"), Cin, C1});
+            if (x1.to) x1.to->raw = true;
+            if (x2 && x2->to) x2->to->raw = true;
+            b2 = bias_of(name + ".conv2", &sc);
+        } else {
+            b2 = bias_of(name + ".conv2");
+        }
+        if (rc) return x1;
+        return conv_tail(s2, Cout, H, W, b2, -1, Cin == Cout ? &x1 : nullptr, name + (Cin != Cout ? ".conv2+sc" : ".conv2"));
+    }
+
+    // Attention block (iadb_bn.py:209-228 AttnDownBlock2D / AttnUpBlock2D, heads of 8 channels): GroupNorm by the
+    // producer, q|k|v + softmax(q k^T / sqrt(8)) v in one launch, to_out + residual in the second
+    Act attention_tail(const Act &x, const std::string &name) {
+        const int C = x.C;
+        wcat_store.emplace_back();
+        std::vector<float> &wcat = wcat_store.back();
+        std::vector<float> bcat;
+        for (const char *p : {".to_q", ".to_k", ".to_v"}) {
+            const std::vector<float> &w = h->hp(name + p + ".weight"), &b = h->hp(name + p + ".bias");
+            wcat.insert(wcat.end(), w.begin(), w.end());
+            bcat.insert(bcat.end(), b.begin(), b.end());
+        }
+        const std::vector<TSrc> sq = normed_sources(x, nullptr, name + ".group_norm", false, TAIL_SEG_1x1, &wcat);
+        if (rc) return x;
+        const float *bq;
+        if ((rc = upload_f32(h, bcat, &bq))) return x;
+        Act att = conv_tail(sq, C, x.H, x.W, bq, -1, nullptr, name + ".qkv+attn", true);
+        if (rc) return x;
+        return conv_tail({TSrc{att, TAIL_SEG_1x1, &h->hp(name + ".to_out.0.weight"), C, 0}}, C, x.H, x.W,
+                         bias_of(name + ".to_out.0"), -1, &x, name + ".to_out");
+    }
+    std::list<std::vector<float>> wcat_store;
+
     const float *bias_of(const std::string &n, const std::string *plus = nullptr) {
         std::vector<float> b = h->hp(n + ".bias");
         if (plus) {
@@ -768,6 +999,7 @@ struct Builder {
             for (int c = 0; c < Cout; ++c) tp_b[temb_cursor + c] += cb[c];
             temb_cursor += Cout;
         }
+        if (tail_ok(H, W)) return resnet_tail(x1, x2, Cout, name, temb_off);
         const float *bias1 = has_temb ? nullptr : bias_of(name + ".conv1");
         if (can_fuse(H, W, Cout)) {
             // conv1: GN(norm1)+SiLU applied to cat(x1, x2) inside the conv prologue
@@ -844,6 +1076,7 @@ struct Builder {
     Act attention(const Act &x, const std::string &name) {
         bndm_unet *hh = h;
         const int C = x.C, H = x.H, W = x.W, T = H * W;
+        if (tail_ok(H, W) && C % 32 == 0) return attention_tail(x, name);
         Act yn = scratch(h->s_y, C, H, W);
         group_norm(x, nullptr, name + ".group_norm", false, yn);
         if (rc) return x;
@@ -954,6 +1187,9 @@ struct Builder {
     }
 
     Act resample(const Act &x, const std::string &name, bool down) {
+        if (tail_ok(down ? x.H / 2 : x.H * 2, down ? x.W / 2 : x.W * 2))
+            return conv_tail({TSrc{x, down ? TAIL_SEG_3x3_S2 : TAIL_SEG_3x3_UP, &h->hp(name + ".weight"), x.C, 0}}, x.C,
+                             down ? x.H / 2 : x.H * 2, down ? x.W / 2 : x.W * 2, bias_of(name), -1, nullptr, name);
         Act out = down ? new_act(x.C, x.H / 2, x.W / 2) : new_act(x.C, x.H * 2, x.W * 2);
         if (!down && can_fuse(out.H, out.W, out.C)) {
             conv_fused({FIn{x, 9, 1, -1}}, {WSeg{&h->hp(name + ".weight"), x.C, 0, x.C, 9}}, nullptr, false, bias_of(name),
@@ -1492,6 +1728,7 @@ extern "C" int bndm_unet_finalize(bndm_unet *h) {
     if (const char *e = getenv("BNDM_NO_GN_SMALL")) b.use_gn_small = !(e[0] == '1');
     if (const char *e = getenv("BNDM_NO_DEFER")) b.use_defer = !(e[0] == '1');
     if (const char *e = getenv("BNDM_NO_GN_INKERNEL")) b.use_gn_inkernel = !(e[0] == '1');
+    if (const char *e = getenv("BNDM_NO_TAIL")) b.use_tail = !(e[0] == '1');       // <= 8x8 levels on igemm + gn_small
     if (const char *e = getenv("BNDM_FUSED_MIN")) b.fused_min = atoi(e);
     if (const char *e = getenv("BNDM_FUSED_MAX")) b.fused_max = atoi(e);
     int rc = h->kind == 1 ? b.build_vae() : b.build();
@@ -1507,6 +1744,8 @@ extern "C" int bndm_unet_finalize(bndm_unet *h) {
     for (Buf &bf : h->bufs) {
         BNDM_CHECK_HIP(hipMalloc(&bf.ptr, bf.bytes ? bf.bytes : 16));
     }
+    for (auto &fn : b.post_alloc)
+        if ((rc = fn())) return rc;
     for (auto &v : h->host) std::vector<float>().swap(v);
     BNDM_CHECK_HIP(hipDeviceSynchronize());
     h->finalized = true;

@@ -160,3 +160,77 @@ int launch_gn_finalize2(const float *p1, int nslab1, int C1, const float *p2, in
                         hipStream_t st);
 
 }  // namespace bndm
+
+// ------------------------------------------------------------------------------------------------
+// conv_s (unet_tail.hip): one launch per convolution of the <= 8x8 levels.  A workgroup owns whole samples x 32 (96)
+// output channels over the full K range (K split across its 8 waves), writes the raw tensor and the GroupNorm(+SiLU)
+// normalised tensor of every consumer, or -- for the attention blocks -- softmax(q k^T / sqrt(8)) v of its four heads.
+// ------------------------------------------------------------------------------------------------
+namespace bndm {
+
+struct TailRound {       // device table entry (8 dwords), one per patch round
+    const void *src;     // NHWC 16-bit source tensor
+    int row_bytes;       // channels * 2 of the source
+    int cbyte;           // first channel of the round * 2
+    int mode;            // 0: same resolution, 1: source at half resolution (nearest-2x), 2: source at double resolution
+    int phase;           // mode 2: 2 * py + px
+    int nsub;            // 32-channel sub-chunks in the round (1..8)
+    int pad;
+};
+
+struct TailNorm {        // one consuming GroupNorm of the produced tensor
+    void *out;           // normalised (+SiLU) 16-bit tensor [M][Cout]
+    const float *gamma, *beta;   // the consumer's affine parameters for THIS tensor's channels
+    int gs;              // channels per group (8, 16 or 32)
+    int silu;
+};
+
+enum TailEpilogue { TAIL_EPI_CONV = 0, TAIL_EPI_ATTN = 1 };
+
+struct TailArgs {
+    const void *wgt;            // weight stream (build_tail_plan)
+    const uint32_t *desc;       // [8 waves][maxsteps]
+    const TailRound *rounds;    // [nrounds]
+    int nrounds, maxsteps;
+    long long tile_bytes;       // weight stream bytes per n-tile
+    int wave_bytes;             // ... per wave
+    int B, hwlog, wlog;         // H * W = 1 << hwlog (4, 16, 64), W = 1 << wlog
+    int Cout, ntn;              // channels per row of the output tensors; n-tiles
+    const float *bias;
+    const float *temb;
+    int temb_bstride, temb_off;
+    const void *resid;          // [M][Cout] 16-bit or nullptr
+    void *raw_out;              // [M][Cout] 16-bit or nullptr
+    int nreq;
+    TailNorm req[3];
+    float eps;
+    int epi;
+    void *attn_out;             // TAIL_EPI_ATTN: [M][Cout] 16-bit attention output (before to_out)
+    unsigned long long *dbg;    // profiling aid: s_memtime marks of workgroup 0 (nullptr in the product path)
+};
+
+enum TailSegKind { TAIL_SEG_3x3 = 0, TAIL_SEG_3x3_UP = 1, TAIL_SEG_3x3_S2 = 2, TAIL_SEG_1x1 = 3 };
+struct TailSeg {
+    int kind;
+    int C;               // channels of the source tensor (multiple of 32)
+};
+struct TailPlanRound {
+    int seg, c0, nsub, mode, phase;
+};
+struct TailPlan {
+    int nrounds = 0, maxsteps = 0, ntn = 0;
+    size_t wave_elems = 0, tile_elems = 0;
+    std::vector<TailPlanRound> rounds;
+    std::vector<uint32_t> desc;
+    std::vector<float> wgt;          // to be converted to 16 bits
+};
+// w_of(segment, weight row, channel within the segment, tap 0..8 (0 for 1x1)) -> fp32 weight;
+// row_of(n-tile, 32-row block, row in block) -> weight row (output channel), or -1 past the end
+TailPlan build_tail_plan(const std::vector<TailSeg> &segs, int Cout_rows, int NB, int D,
+                         const std::function<float(int, int, int, int)> &w_of,
+                         const std::function<int(int, int, int)> &row_of);
+int tail_ring_depth(int nb);
+// TM x (32 NB): 128 x 32, 64 x 32, 64 x 96
+int launch_conv_tail(int dtype, int TM, int NB, const TailArgs &a, hipStream_t st);
+
+}  // namespace bndm
