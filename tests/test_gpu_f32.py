@@ -80,7 +80,8 @@ def test_fp32_mode_loops_match_oracle_loops():
     xr = x0.clone()
     for t in ts[:3]:
         xr = S.ddim_step(U.forward(sdd, cfgd, xr, int(t)), int(t), xr, acp, ratio)
-    xg = sch.sample  # noqa: F841  (the in-engine loop is covered by test_gpu_unet; here: step by step)
+    # step by step here; the in-engine loop (sch.sample -> bndm_unet_sample_ddim) is compared with the oracle loop and with
+    # this step-by-step form in tests/test_gpu_tail.py::test_ddim_in_engine_loop_matches_oracle_loop
     xg = x0.cuda()
     for t in sch.timesteps[:3]:
         xg = sch.step(md(xg, int(t)).sample, int(t), xg).prev_sample
