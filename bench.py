@@ -222,6 +222,50 @@ def make_workload(name, B, N, dtype, dev):
     raise SystemExit(f"unknown --config {name}")
 
 
+def short_pass(name, dtype, dev, lib, timed=2):
+    """One BASELINE.json configuration at its per-GPU size: 1 warm-up + `timed` passes of the whole path, plus the
+    forward's event-timed duration and TFLOP/s (algorithmic 2*MAC of the engine's launch list)."""
+    import torch
+    from bndm_amd import _lib
+    from bndm_amd.unet import engine_ops
+    wl = make_workload(name, 0, 0, dtype, dev)
+    B, N, model = wl["B"], wl["N"], wl["model"]
+    wl["one_pass"]()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        wl["one_pass"]()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / timed
+    res, cin, cout = wl["res"], wl["cin"], wl["cout"]
+    h = model._ensure_engine(B, res, dev)
+    prof = _lib.UNetProfile()
+    xs = torch.randn(B, cin, res, res, device=dev)
+    ts = torch.full((B,), 0.5, device=dev)
+    od = torch.empty(B, cout, res, res, device=dev)
+    _lib.check(lib.bndm_unet_profile(h, C.c_void_p(xs.data_ptr()), C.c_void_p(ts.data_ptr()), C.c_void_p(od.data_ptr()), B, 3,
+                                     C.byref(prof), _lib.current_stream_ptr()), "bndm_unet_profile")
+    flops = sum(f for _, _, f in engine_ops(h)) * B
+    tf = flops / (prof.ms_total * 1e-3) / 1e12
+    out = {"workload": wl["workload"], "value": round(B / el, 3), "unit": "images/sec", "batch_per_gpu": B, "nb_steps": N,
+           "ms_per_step": round(el * 1e3, 2), "ms_per_forward": round(prof.ms_total, 3), "launches_per_forward": prof.launches,
+           "tflops": round(tf, 1), "frac_of_peak": round(tf / PEAK_F16_TFLOPS, 4)}
+    if "vae" in wl:
+        from bndm_amd.vae import vae_decode
+        lat = 0.18215 * torch.randn(B, 4, 64, 64, device=dev)
+        vae_decode(wl["vae"], lat)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(2):
+            vae_decode(wl["vae"], lat)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 2
+        out["vae_decode_ms_per_batch"] = round(ms, 2)
+        out["vae_decode_tflops"] = round(2.51e12 * B / (ms * 1e-3) / 1e12, 1)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -233,10 +277,20 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-only", action="store_true", help="skip the timed passes; only the per-kernel profile")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short c3 / c4 / c5 passes that follow the timed c2 region (other_configs)")
+    ap.add_argument("--allow-ablation", action="store_true",
+                    help="profiling tools only (tools/ablate.sh): run although BNDM_ABLATE is set; the line is marked invalid")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="test hook: exercise the rank launch / barrier / max-over-ranks plumbing on CPU (gloo), no compute")
     argv = sys.argv[1:]
     args = ap.parse_args(argv)
+
+    # switches of the library that are present in the environment are reported with the line; the ablation switch of the
+    # profiling build (kernels with work removed) is refused outright
+    env_seen = {k: v for k, v in sorted(os.environ.items()) if k.startswith("BNDM_")}
+    if "BNDM_ABLATE" in env_seen and not args.allow_ablation:
+        raise SystemExit("bench.py: BNDM_ABLATE is set (profiling switch of tools/ablate.sh): refusing to benchmark")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, argv))
@@ -268,6 +322,7 @@ def main():
     torch.manual_seed(1234 + rank)
     wl = make_workload(args.config, args.batch, args.nb_steps, args.dtype, dev)
     B, N, model = wl["B"], wl["N"], wl["model"]
+    metric_name, workload_name = wl["metric"], wl["workload"]
 
     def one_pass():
         return gather_images(wl["one_pass"](), dst=0)
@@ -368,20 +423,34 @@ def main():
         stages = dict(stages or {}, vae_decode_ms_per_batch=round(ms, 2), vae_decode_tflops=round(vae_tf, 1),
                       vae_decode_frac_of_mfma_peak=round(vae_tf / PEAK_F16_TFLOPS, 4))
 
+    # ---- the other BASELINE.json configurations at their per-GPU sizes, short passes after the timed c2 region ------
+    others = None
+    if rank == 0 and args.config == "c2" and args.gpus == 1 and not (args.profile_only or args.no_other_configs):
+        others = {}
+        del wl, model
+        torch.cuda.empty_cache()
+        for oc in ("c3", "c4", "c5"):
+            others[oc] = short_pass(oc, args.dtype, dev, lib)
+            torch.cuda.empty_cache()
+        wl = None
+
     if rank == 0:
         imgs = args.gpus * B * args.steps
         base = None
         if not (args.no_cpu_baseline or args.gpus > 1 or args.profile_only):
             base = cpu_baseline()
         line = {
-            "metric": wl["metric"],
+            "metric": metric_name,
             "value": round(imgs / elapsed, 3), "unit": "images/sec", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": wl["workload"], "baseline_config": args.config,
+            "config": {"workload": workload_name, "baseline_config": args.config,
                        "global_batch": B * args.gpus, "nb_steps": N, "parallelism": f"batch-shard x{args.gpus}"},
             "roofline": roof,
             "stages": stages,
+            # c3 / c4 / c5 at their per-GPU batch (1 warm-up + 2 timed passes each), same library, same process
+            "other_configs": others,
+            "env": env_seen,
             # timed on rank 0 of the single-GPU run only (the host cores are shared by the ranks otherwise)
             "cpu_baseline": base,
         }

@@ -794,13 +794,6 @@ int launch_t32_t(const FusedArgs &a, hipStream_t st) {
         BNDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_t32<T, TH, ABL, NW, NCO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr = true;
-        if (getenv("BNDM_T32_DEBUG")) {
-            int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&conv_t32<T, TH, ABL, NW, NCO>),
-                                                               NW * 64, smem);
-            fprintf(stderr, "[bndm] conv_t32<TH=%d, NW=%d>: %d B of LDS, %d resident workgroups per CU (occupancy query)\n",
-                    TH, NW, smem, nb);
-        }
     }
     const int tiles_x = a.W / 16, tiles_y = a.H / TH, tps = tiles_x * tiles_y, ntn = (a.Cout + NCO - 1) / NCO;
     int nsteps = 0;
@@ -813,31 +806,9 @@ int launch_t32_t(const FusedArgs &a, hipStream_t st) {
         dbg = buf;
     }
     hipLaunchKernelGGL((conv_t32<T, TH, ABL, NW, NCO>), grid, dim3(NW * 64), smem, st, a, tiles_x, tps, ntn, nsteps, dbg);
-    if constexpr ((ABL & 64) != 0) {
-        // profiling aid: dump the marks of 8-chunk launches (the K = 2304 layers) as text
-        int n9 = 0;
-        for (int i = 0; i < a.nseg; ++i) n9 += a.seg[i].taps == 9 ? a.seg[i].C / 32 : 0;
-        if (n9 == 8 && getenv("BNDM_T32_TRACE")) {
-            unsigned h[4 * 9 * 6 + 32];
-            BNDM_CHECK_HIP(hipStreamSynchronize(st));
-            BNDM_CHECK_HIP(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
-            FILE *f = fopen(getenv("BNDM_T32_TRACE"), "w");
-            if (f) {
-                for (int w = 0; w < 4; ++w)
-                    for (int t = 0; t < 9; ++t) {
-                        fprintf(f, "w%d t%d", w, t);
-                        for (int k = 0; k < 5; ++k) fprintf(f, " %u", h[(w * 9 + t) * 6 + k] - h[0]);
-                        fprintf(f, "\n");
-                    }
-                for (int blk = 0; blk < 2; ++blk) {
-                    fprintf(f, "life blk%d", blk ? 700 : 0);
-                    for (int k = 0; k < 6; ++k) fprintf(f, " %u", h[216 + 16 * blk + k] - h[216]);
-                    fprintf(f, "\n");
-                }
-                fclose(f);
-            }
-        }
-    }
+#ifdef BNDM_ABLATION      // profiling builds only (tools/ablate.sh)
+#include "ablation_t32_trace.inc"
+#endif
     return launch_status("conv_t32");
 }
 
@@ -897,8 +868,6 @@ std::vector<float> pack_weights_t32(const FusedSeg *seg, int nseg, int Cout,
 }
 
 int launch_conv_t32(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
-    static const int abl = getenv("BNDM_ABLATE") ? atoi(getenv("BNDM_ABLATE")) : 0;
-    static const int nw_env = getenv("BNDM_T32_NW") ? atoi(getenv("BNDM_T32_NW")) : 0;
     // two 4-wave workgroups per CU need a grid of at least ~two per CU; smaller grids get 8-wave workgroups
     if (a.out_nchw32) {                              // network head: 32-channel tiles, fp32 NCHW output
         if (dtype == BNDM_DTYPE_F16)
@@ -906,22 +875,11 @@ int launch_conv_t32(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
         return TH == 16 ? launch_t32_t<__bf16, 16, 0, 4, 32>(a, st) : launch_t32_t<__bf16, 8, 0, 4, 32>(a, st);
     }
     const long long nblk = (long long)a.B * (a.H / TH) * (a.W / 16) * (a.Cout / 128);
-    const int nw = nw_env ? nw_env : (nblk >= 448 ? 4 : 8);
+    const int nw = nblk >= 448 ? 4 : 8;
     if (dtype == BNDM_DTYPE_F16) {
-        if (abl && TH == 16 && nw == 4) {
-            switch (abl) {
-                case 1: return launch_t32_t<_Float16, 16, 1>(a, st);
-                case 2: return launch_t32_t<_Float16, 16, 2>(a, st);
-                case 4: return launch_t32_t<_Float16, 16, 4>(a, st);
-                case 8: return launch_t32_t<_Float16, 16, 8>(a, st);
-                case 16: return launch_t32_t<_Float16, 16, 16>(a, st);
-                case 14: return launch_t32_t<_Float16, 16, 14>(a, st);
-                case 15: return launch_t32_t<_Float16, 16, 15>(a, st);
-                case 64: return launch_t32_t<_Float16, 16, 64>(a, st);
-                case 512: return launch_t32_t<_Float16, 16, 512>(a, st);
-                default: break;
-            }
-        }
+#ifdef BNDM_ABLATION      // profiling builds only (tools/ablate.sh)
+#include "ablation_t32_dispatch.inc"
+#endif
         if (nw == 8) return TH == 16 ? launch_t32_t<_Float16, 16, 0, 8>(a, st) : launch_t32_t<_Float16, 8, 0, 8>(a, st);
         return TH == 16 ? launch_t32_t<_Float16, 16, 0>(a, st) : launch_t32_t<_Float16, 8, 0>(a, st);
     }

@@ -60,14 +60,12 @@ struct ConvPlan {
 static ConvPlan plan_conv(int M, int Cout, int ksteps, size_t splitk_bytes) {
     int tile = TILE_256x128;
     int nblk = ceil_div(M, 256) * ceil_div(Cout, 128);
-    static const int big_min_m = getenv("BNDM_SPLITK_BIG_M") ? atoi(getenv("BNDM_SPLITK_BIG_M")) : (1 << 30);
-    if (nblk < 192 && M < big_min_m) {
+    if (nblk < 192) {
         tile = TILE_128x128;
         nblk = ceil_div(M, 128) * ceil_div(Cout, 128);
     }
     int splitk = 1;
-    static const int sk_target = getenv("BNDM_SPLITK_TARGET") ? atoi(getenv("BNDM_SPLITK_TARGET")) : 256;
-    static const int sk_minsteps = getenv("BNDM_SPLITK_MINSTEPS") ? atoi(getenv("BNDM_SPLITK_MINSTEPS")) : 8;
+    constexpr int sk_target = 256, sk_minsteps = 8;      // workgroups aimed at, K-steps a slice keeps at least
     if (nblk < 192 && ksteps >= 8) {
         splitk = std::min(std::min(ceil_div(sk_target, nblk), ksteps / sk_minsteps), 32);
         if (splitk >= 2) {
@@ -530,6 +528,14 @@ struct Builder {
     bool can_fuse(int H, int W, int Cout) const {
         return use_fused && H >= 16 && W >= 16 && H >= fused_min && H <= fused_max && Cout % 128 == 0;
     }
+    // what conv_t32 can take (conv_t32_supports): a scale / shift table of at most 512 channels, at most 32 chunks of 32
+    // channels per launch, source tensors below 2 GiB.  Layers outside (e.g. an up-block concat of 2 x 512 channels at
+    // >= 16x16) run on the implicit-GEMM convolution + materialised GroupNorm instead.
+    bool fits_t32(int Cin, int Cout, int H, int W) const {
+        const long long px = (long long)h->cfg.max_batch * H * W;
+        const int chunks2 = Cout / 32 + (Cin != Cout ? Cin / 32 : 0);
+        return Cin <= 512 && Cout <= 512 && Cin / 32 <= 32 && chunks2 <= 32 && px * std::max(Cin, Cout) * 2 < (1LL << 31);
+    }
     void conv_fused(const std::vector<FIn> &ins, const std::vector<WSeg> &ws, const GnSpec *gs, bool silu,
                     const float *bias, int temb_off, const Act *resid, const Act &out, bool want_stats,
                     const std::string &label, bool head = false) {
@@ -693,9 +699,8 @@ struct Builder {
         {
             double act = 0;
             for (const SegIn &f : ins) act += (double)h->cfg.max_batch * f.a.H * f.a.W * f.a.C;
-            static const int wm = getenv("BNDM_WMAJOR") ? atoi(getenv("BNDM_WMAJOR")) : 1;
-            a.wmajor = wm && (double)out.C * Ktot > act ? 1 : 0;
-            a.wtiled = 1;                                // every caller packs with pack_conv_weight(..., 128, ...)
+            a.wmajor = (double)out.C * Ktot > act ? 1 : 0;
+            a.wtiled = Ktot % 64 == 0 ? 1 : 0;           // pack_conv_weight(..., 128, ...) tiles exactly then
         }
         {
             bool any_up = false;
@@ -1001,7 +1006,7 @@ struct Builder {
         }
         if (tail_ok(H, W)) return resnet_tail(x1, x2, Cout, name, temb_off);
         const float *bias1 = has_temb ? nullptr : bias_of(name + ".conv1");
-        if (can_fuse(H, W, Cout)) {
+        if (can_fuse(H, W, Cout) && fits_t32(Cin, Cout, H, W)) {
             // conv1: GN(norm1)+SiLU applied to cat(x1, x2) inside the conv prologue
             const GnSpec g1 = gn_table(x1, x2, name + ".norm1");
             if (rc) return x1;
@@ -1191,7 +1196,7 @@ struct Builder {
             return conv_tail({TSrc{x, down ? TAIL_SEG_3x3_S2 : TAIL_SEG_3x3_UP, &h->hp(name + ".weight"), x.C, 0}}, x.C,
                              down ? x.H / 2 : x.H * 2, down ? x.W / 2 : x.W * 2, bias_of(name), -1, nullptr, name);
         Act out = down ? new_act(x.C, x.H / 2, x.W / 2) : new_act(x.C, x.H * 2, x.W * 2);
-        if (!down && can_fuse(out.H, out.W, out.C)) {
+        if (!down && can_fuse(out.H, out.W, out.C) && fits_t32(x.C, x.C, out.H, out.W)) {
             conv_fused({FIn{x, 9, 1, -1}}, {WSeg{&h->hp(name + ".weight"), x.C, 0, x.C, 9}}, nullptr, false, bias_of(name),
                        -1, nullptr, out, true, name);
             return out;
@@ -1493,6 +1498,7 @@ struct Builder {
                                           cc.out = hh->P(hh->s_tp);
                                           return launch_conv(hh->dtype(), TILE_128x128, EPI_F32_ROWS, cc, r.st);
                                       }, "conv time_emb_proj (all resnets)"};
+            h->ops[temb_proj_op].kernel = "conv_igemm";
         }
         return 0;
     }
@@ -1727,10 +1733,7 @@ extern "C" int bndm_unet_finalize(bndm_unet *h) {
     if (const char *e = getenv("BNDM_NO_FUSED")) b.use_fused = !(e[0] == '1');     // debugging: igemm + gn_apply everywhere
     if (const char *e = getenv("BNDM_NO_GN_SMALL")) b.use_gn_small = !(e[0] == '1');
     if (const char *e = getenv("BNDM_NO_DEFER")) b.use_defer = !(e[0] == '1');
-    if (const char *e = getenv("BNDM_NO_GN_INKERNEL")) b.use_gn_inkernel = !(e[0] == '1');
     if (const char *e = getenv("BNDM_NO_TAIL")) b.use_tail = !(e[0] == '1');       // <= 8x8 levels on igemm + gn_small
-    if (const char *e = getenv("BNDM_FUSED_MIN")) b.fused_min = atoi(e);
-    if (const char *e = getenv("BNDM_FUSED_MAX")) b.fused_max = atoi(e);
     int rc = h->kind == 1 ? b.build_vae() : b.build();
     if (rc) return rc;
     {

@@ -772,40 +772,9 @@ int launch_conv_cfg2(const ConvArgs &a, hipStream_t st) {
         attr = true;
     }
     dim3 grid(ntm * ntn, a.splitk > 1 ? a.splitk : 1);
-    if (getenv("BNDM_IGEMM_TRACE")) {
-        // profiling aid: marks of the first launch whose K-step count equals BNDM_IGEMM_TRACE_KSTEPS are dumped as text
-        static unsigned *buf = nullptr;
-        static bool done = false;
-        const int want = getenv("BNDM_IGEMM_TRACE_KSTEPS") ? atoi(getenv("BNDM_IGEMM_TRACE_KSTEPS")) : 144;
-        if (!done && ksteps == want) {
-            if (!buf) BNDM_CHECK_HIP(hipMalloc(&buf, (16 * 24 * 5 + 64) * sizeof(unsigned)));
-            BNDM_CHECK_HIP(hipMemsetAsync(buf, 0, (16 * 24 * 5 + 64) * sizeof(unsigned), st));
-            ConvArgs t = a;
-            t.counters = buf;
-            hipLaunchKernelGGL((conv_igemm<T, WM, WN, TM, TN, EPI, STAGES, FAST>), grid, dim3(WM * WN * 64), smem, st, t,
-                               ksteps, ilog2(a.W), ilog2(a.H), ntm, ntn);
-            BNDM_CHECK_HIP(hipStreamSynchronize(st));
-            unsigned hbuf[16 * 24 * 5 + 64];
-            BNDM_CHECK_HIP(hipMemcpy(hbuf, buf, sizeof(hbuf), hipMemcpyDeviceToHost));
-            if (FILE *f = fopen(getenv("BNDM_IGEMM_TRACE"), "w")) {
-                fprintf(f, "# waves %d tile %dx%d splitk %d ksteps %d grid %d M=%d N=%d\n", WM * WN, WM * TM * 32, WN * TN * 32,
-                        a.splitk, ksteps, ntm * ntn, a.B * a.H * a.W, a.Cout);
-                for (int w = 0; w < WM * WN; ++w)
-                    fprintf(f, "w%d life: entry %d loop-end %u stores-retired %u (relative to the first K-step mark of wave 0)\n", w,
-                            (int)(hbuf[16 * 24 * 5 + w * 4] - hbuf[0]), hbuf[16 * 24 * 5 + w * 4 + 1] - hbuf[0],
-                            hbuf[16 * 24 * 5 + w * 4 + 2] - hbuf[0]);
-                for (int w = 0; w < WM * WN; ++w)
-                    for (int it = 0; it < 24; ++it) {
-                        fprintf(f, "w%d s%d", w, it);
-                        for (int k = 0; k < 5; ++k) fprintf(f, " %u", hbuf[(w * 24 + it) * 5 + k] - hbuf[0]);
-                        fprintf(f, "\n");
-                    }
-                fclose(f);
-            }
-            done = true;
-            return launch_status("conv_igemm");
-        }
-    }
+#ifdef BNDM_ABLATION      // profiling builds only (tools/ablate.sh)
+#include "ablation_igemm_trace.inc"
+#endif
     hipLaunchKernelGGL((conv_igemm<T, WM, WN, TM, TN, EPI, STAGES, FAST>), grid, dim3(WM * WN * 64), smem, st, a,
                        ksteps, ilog2(a.W), ilog2(a.H), ntm, ntn);
     return launch_status("conv_igemm");
@@ -816,9 +785,15 @@ int launch_conv_cfg(const ConvArgs &a, hipStream_t st) {
     // the table-driven path pays ~100 VALU of per-piece set-up: only worth it with enough K-steps per block
     int ksteps = 0;
     for (int i = 0; i < a.nseg; ++i) ksteps += a.seg[i].taps * (a.seg[i].C / 64);
-    static const int fast_min = getenv("BNDM_IGEMM_FAST_MIN") ? atoi(getenv("BNDM_IGEMM_FAST_MIN")) : 4;
+    constexpr int fast_min = 4;
     bool fast = a.steps != nullptr && ksteps / (a.splitk > 1 ? a.splitk : 1) >= fast_min;
-    for (int i = 0; i < a.nseg; ++i) fast = fast && !a.seg[i].up;
+    for (int i = 0; i < a.nseg; ++i) {
+        fast = fast && !a.seg[i].up;
+        // the table-driven path addresses a source through a buffer descriptor with 32-bit offsets
+        const long long bytes = (long long)a.B * a.H * a.stride * a.W * a.stride * a.seg[i].C * 2 +
+                                (long long)(a.W * a.stride + 1) * a.seg[i].C * 2;
+        fast = fast && bytes < (1LL << 31);
+    }
     return fast ? launch_conv_cfg2<T, WM, WN, TM, TN, EPI, STAGES, true>(a, st)
                 : launch_conv_cfg2<T, WM, WN, TM, TN, EPI, STAGES, false>(a, st);
 }
@@ -828,12 +803,9 @@ int launch_conv_t(int tile, int epi, const ConvArgs &a, hipStream_t st) {
     if (tile == TILE_256x128) {      // 8 waves, 3-stage ring (144 KB LDS, one block per CU)
         if (epi == EPI_NHWC16) return launch_conv_cfg<T, 4, 2, 2, 2, EPI_NHWC16, 3>(a, st);
         if (epi == EPI_F32_ROWS) return launch_conv_cfg<T, 4, 2, 2, 2, EPI_F32_ROWS, 3>(a, st);
-    } else if (tile == TILE_128x128) {   // 4-stage ring (128 KB LDS); 8 waves (32x64 wave tiles) or 4 (64x64)
-        static const int w8 = getenv("BNDM_IGEMM_W8") ? atoi(getenv("BNDM_IGEMM_W8")) : 1;
-        if (w8 && epi == EPI_NHWC16) return launch_conv_cfg<T, 4, 2, 1, 2, EPI_NHWC16, 4>(a, st);
-        if (w8 && epi == EPI_F32_ROWS) return launch_conv_cfg<T, 4, 2, 1, 2, EPI_F32_ROWS, 4>(a, st);
-        if (epi == EPI_NHWC16) return launch_conv_cfg<T, 2, 2, 2, 2, EPI_NHWC16, 4>(a, st);
-        if (epi == EPI_F32_ROWS) return launch_conv_cfg<T, 2, 2, 2, 2, EPI_F32_ROWS, 4>(a, st);
+    } else if (tile == TILE_128x128) {   // 4-stage ring (128 KB LDS), 8 waves (32x64 wave tiles)
+        if (epi == EPI_NHWC16) return launch_conv_cfg<T, 4, 2, 1, 2, EPI_NHWC16, 4>(a, st);
+        if (epi == EPI_F32_ROWS) return launch_conv_cfg<T, 4, 2, 1, 2, EPI_F32_ROWS, 4>(a, st);
     } else if (tile == TILE_128x32) {    // 4 waves, 4-stage ring (80 KB LDS)
         if (epi == EPI_NCHW32) return launch_conv_cfg<T, 4, 1, 1, 1, EPI_NCHW32, 4>(a, st);
         if (epi == EPI_NHWC16) return launch_conv_cfg<T, 4, 1, 1, 1, EPI_NHWC16, 4>(a, st);
@@ -852,6 +824,10 @@ inline int grid_for(size_t n) {
 #define DISPATCH_T(dtype, expr_f16, expr_bf16) ((dtype) == BNDM_DTYPE_F16 ? (expr_f16) : (expr_bf16))
 
 int launch_conv(int dtype, int tile, int epi, const ConvArgs &a, hipStream_t st) {
+    if (a.wtiled && tile == TILE_128x32) {
+        set_error("conv_igemm: tile-contiguous weights are packed for 128-row tiles");
+        return BNDM_E_ARG;
+    }
     for (int i = 0; i < a.nseg; ++i)
         if (a.seg[i].C % 64 != 0 || (a.seg[i].taps != 1 && a.seg[i].taps != 9)) {
             set_error("launch_conv: segment %d has C=%d taps=%d", i, a.seg[i].C, a.seg[i].taps);

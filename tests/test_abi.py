@@ -51,3 +51,31 @@ def test_product_path_fails_loudly_without_gpu():
     x = torch.zeros(1, 3, 64, 64)
     with pytest.raises(_lib.BndmError):
         get_noise_v2(torch.device("cpu"), x, torch.eye(4096), torch.zeros(1), None, "gaussianBN", "test", True)
+
+
+def test_product_library_has_no_ablation_kernels_and_few_switches():
+    """The wrong-result profiling variants of conv_t32 (template argument ABL != 0) are compiled only into
+    tools/libbndm_ablate.so (-DBNDM_ABLATION); the product library holds ABL = 0 instantiations only, and its sources
+    read at most eight environment switches."""
+    from bndm_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    names = set(re.findall(rb"conv_t32IDF16b?_?Li(\d+)ELi(\d+)E", blob))
+    assert names, "conv_t32 kernels not found in the library"
+    assert {abl for _, abl in names} == {b"0"}, sorted(names)
+    n = 0
+    csrc = os.path.join(ROOT, "bndm_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith(".hip"):
+            n += open(os.path.join(csrc, f)).read().count("getenv")
+    assert n <= 8, n
+
+
+def test_bench_refuses_the_ablation_switch_and_reports_switches():
+    import subprocess
+    import sys
+    env = dict(os.environ, BNDM_ABLATE="15")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-cpu"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "BNDM_ABLATE" in (r.stderr + r.stdout)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"env": env_seen' in src and '"other_configs": others' in src

@@ -193,3 +193,26 @@ def test_c5_chain_latent_noise_loop_decode_export(formula_L):
     psnr = 10 * np.log10(255.0 ** 2 / max(mse, 1e-12))
     print(f"c5 chain decoded images: PSNR {psnr:.1f} dB")
     assert psnr >= 35.0
+
+
+def test_wide_concat_at_16x16_falls_back_to_igemm():
+    """block_out_channels (128, 512, 512) at 32 px: the 16x16 up-block concatenates 512 + 512 channels, beyond conv_t32's
+    scale / shift table -- those layers must run on the implicit-GEMM convolution + GroupNorm instead of failing at
+    bndm_unet_finalize (diffusers accepts any such configuration; google/ddpm-*-256 has a 1024-channel concat)."""
+    from oracle import unet_oracle as U
+    from bndm_amd.unet import UNet2DModel
+    boc = (128, 512, 512)
+    cfg = dict(in_channels=3, out_channels=3, block_out_channels=boc, down_attn=(False,) * 3, up_attn=(False,) * 3,
+               layers_per_block=2)
+    sd = U.init_params(cfg, seed=5, perturb_norm=0.1)
+    m = UNet2DModel(in_channels=3, out_channels=3, block_out_channels=boc, down_block_types=("DownBlock2D",) * 3,
+                    up_block_types=("UpBlock2D",) * 3)
+    m.load_state_dict(sd)
+    m = m.to("cuda").eval()
+    x = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(1))
+    t = torch.tensor([0.7, 0.2])
+    ref = U.forward(sd, cfg, x, t)
+    got = m(x.cuda(), t.cuda(), return_dict=False)[0].cpu()
+    kinds = {(k, lab.split()[-1]) for k, lab, _ in _ops(m, 2, 32)}
+    assert ("conv_igemm", "16x16") in kinds and ("conv_t32<TH=8>", "32x32") in kinds, sorted(kinds)
+    assert _rel(got, ref) <= 2e-3
