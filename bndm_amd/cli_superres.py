@@ -81,13 +81,16 @@ def run_conditional(opt, device, rank, world):
     psnr_sum, ssim_sum, l1_sum, l2_sum, cnt = 0.0, 0.0, 0.0, 0.0, 0
     from .metrics import ssim
     from PIL import Image
-    for order, idx in enumerate(picks):
+    produced = 0
+    for idx in picks:
         if idx > len(targets):
             continue
         # every rank consumes the draw of every pick (the reference's single numpy stream, iadb_bn.py:631), so the
         # images do not depend on the number of ranks; a rank keeps the picks it owns
         x0_np = np.random.randn(1, 3, opt.res, opt.res)
-        cnt_name = order + 1                                              # running cnt of iadb_bn.py:662
+        order = produced
+        produced += 1
+        cnt_name = produced                                               # running cnt of iadb_bn.py:662: images produced
         if order % world != rank:
             continue
         x1 = torch.from_numpy(targets[idx - 1])[None].to(device) * 2 - 1
@@ -118,7 +121,13 @@ def run_conditional(opt, device, rank, world):
                 os.path.join(out_dir, folder, "highres", f"highres_{tag}_{cnt_name:05d}.png"))
             Image.fromarray(export_u8(x_c, "trunc")[0].cpu().numpy()).save(
                 os.path.join(out_dir, folder, "lowres", f"lowres_{tag}_{cnt_name:05d}.png"))
-    if cnt:
-        print(f"[rank {rank}] conditional metrics over {cnt} images: ssim {ssim_sum / cnt:.4f}, psnr {psnr_sum / cnt:.4f}, "
-              f"l1 {l1_sum / cnt:.2f}, l2 {l2_sum / cnt:.2f}")
+    # the averages cover every image of every rank (iadb_bn.py:681 prints one line for the whole test set)
+    sums = torch.tensor([ssim_sum, psnr_sum, l1_sum, l2_sum, float(cnt)], dtype=torch.float64, device=device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(sums)
+    tot = int(sums[4].item())
+    if tot and rank == 0:
+        a = (sums[:4] / sums[4]).tolist()
+        print(f"conditional metrics over {tot} images: ssim {a[0]:.4f}, psnr {a[1]:.4f}, l1 {a[2]:.2f}, l2 {a[3]:.2f}")
     return 0

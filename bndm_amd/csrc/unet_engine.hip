@@ -892,6 +892,7 @@ struct Builder {
         a.rounds = (const TailRound *)dRounds;
         a.nrounds = plan.nrounds;
         a.maxsteps = plan.maxsteps;
+        for (int i = 0; i < 8; ++i) a.nuse[i] = plan.nuse[i];
         a.tile_bytes = (long long)plan.tile_elems * 2;
         a.wave_bytes = (int)(plan.wave_elems * 2);
         a.hwlog = 31 - __builtin_clz(HW);
@@ -906,9 +907,20 @@ struct Builder {
         const std::shared_ptr<TailOut> to = out.to;
         cur_name = S("cnvS %-44s K=%-5d N=%-4d %dx%d", label.c_str(), (int)mac, rows, H, W);
         const size_t op_index = h->ops.size();
+        std::vector<int> rslots, rcs;
+        for (const TSrc &t : srcs) {
+            rslots.push_back(t.a.slot);
+            rcs.push_back(t.a.C);
+        }
+        const std::vector<TailPlanRound> prs(plan.rounds.begin(), plan.rounds.begin() + std::min(2, plan.nrounds));
         push(OPC_CONV, 2.0 * mac * rows * HW + (qkv ? 4.0 * HW * HW * Cout : 0.0), [=](RunCtx &r) {
             TailArgs c = a;
             c.B = r.B;
+            for (size_t i = 0; i < prs.size(); ++i) {
+                TailRound &d = i ? c.r1 : c.r0;
+                d = TailRound{hh->P(rslots[prs[i].seg]), rcs[prs[i].seg] * 2, prs[i].c0 * 2, prs[i].mode, prs[i].phase,
+                              prs[i].nsub, 0};
+            }
             c.temb = temb_off >= 0 ? (r.tp_row ? r.tp_row : (const float *)hh->P(hh->s_tp)) : nullptr;
             c.temb_bstride = r.tp_row ? 0 : hh->ntemb;
             c.resid = rs >= 0 ? hh->P(rs) : nullptr;

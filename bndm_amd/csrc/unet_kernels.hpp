@@ -191,7 +191,9 @@ struct TailArgs {
     const void *wgt;            // weight stream (build_tail_plan)
     const uint32_t *desc;       // [8 waves][maxsteps]
     const TailRound *rounds;    // [nrounds]
+    TailRound r0, r1;           // copies of rounds[0], rounds[1] (r1 unused when nrounds == 1)
     int nrounds, maxsteps;
+    int nuse[8];                // entries of each wave's list up to its last real / boundary entry
     long long tile_bytes;       // weight stream bytes per n-tile
     int wave_bytes;             // ... per wave
     int B, hwlog, wlog;         // H * W = 1 << hwlog (4, 16, 64), W = 1 << wlog
@@ -219,6 +221,7 @@ struct TailPlanRound {
 };
 struct TailPlan {
     int nrounds = 0, maxsteps = 0, ntn = 0;
+    int nuse[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     size_t wave_elems = 0, tile_elems = 0;
     std::vector<TailPlanRound> rounds;
     std::vector<uint32_t> desc;

@@ -124,7 +124,42 @@ __global__ __launch_bounds__(TS_NT) void conv_s(const TailArgs a) {
     const int Cout = a.Cout, n0 = nt * TN;
     const bool attn = a.epi == TAIL_EPI_ATTN;
 
-    // ---- epilogue rows, requested first (oldest loads): bias + time-embedding row per (sample of the tile, channel),
+    // ---- patch DMA of one round --------------------------------------------------------------------------------------
+    // DMA instruction i of wave w fills LDS rows 2 (w NDMA + i), +1 (lane >> 5); physical slot p = lane & 31 of row R
+    // holds logical 16-byte slot p ^ (R & 15)
+    const TailRound *__restrict__ rtab = a.rounds;
+    auto round_dma_desc = [&](uint64_t src, int row_bytes, int cbyte, int mode, int phase, int nsub, int buf) {
+        const int rows_src = mode == 0 ? M : (mode == 1 ? M >> 2 : M << 2);
+        const __amdgpu_buffer_rsrc_t rs = uniform_rsrc((const void *)src, rows_src * row_bytes);
+        const int py = phase >> 1, px = phase & 1;
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int R = (w * NDMA + i) * 2 + kh;
+            const int s = q ^ (R & 15);
+            const int m = m0 + R;
+            const int b = m >> hwlog, pix = m & (HW - 1), y = pix >> wlog, x = pix & (Wd - 1);
+            int srow = m;
+            if (mode == 1) srow = ((b << (hwlog - 2)) + ((y >> 1) << (wlog - 1))) + (x >> 1);
+            if (mode == 2) srow = ((((b * Hd + y) * 2 + py) << (wlog + 1)) + 2 * x + px);
+            const bool ok = m < M && s < nsub * 4;
+            const unsigned voff = ok ? (unsigned)(srow * row_bytes + cbyte + s * 16) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + buf * PB + (w * NDMA + i) * 1024), 16, voff, 0,
+                                                     0, 0);
+        }
+    };
+    // rounds 0 and 1 are described in the kernel arguments (no dependent scalar load in front of the first DMA), later
+    // ones in the device table
+    auto round_dma = [&](int r, int buf) {
+        const const_u32_ptr rp = (const_u32_ptr)(rtab + r);
+        const u32x8 e = *reinterpret_cast<const __attribute__((address_space(4))) u32x8 *>(rp);
+        round_dma_desc(((uint64_t)e[1] << 32) | e[0], (int)e[2], (int)e[3], (int)e[4], (int)e[5], (int)e[6], buf);
+    };
+
+    const int nrounds = a.nrounds;
+    round_dma_desc((uint64_t)a.r0.src, a.r0.row_bytes, a.r0.cbyte, a.r0.mode, a.r0.phase, a.r0.nsub, 0);
+    mark(8);
+
+    // ---- epilogue rows, requested right behind the first patch round: bias + time-embedding row per (sample of the tile, channel),
     // gamma / beta of the consuming GroupNorms; stored to LDS further down
     // channel of column c: plain tiles n0 + c; q|k|v tiles (c / 32) * C + 32 nt + c % 32
     float *rows = reinterpret_cast<float *>(smem + OFF_ROWS);         // [16][TN] additive, then [3][2][TN] gamma / beta
@@ -151,52 +186,33 @@ __global__ __launch_bounds__(TS_NT) void conv_s(const TailArgs a) {
         if (r < a.nreq) gbv = gp[n0 + c];
     }
 
-    // ---- patch DMA of one round --------------------------------------------------------------------------------------
-    // DMA instruction i of wave w fills LDS rows 2 (w NDMA + i), +1 (lane >> 5); physical slot p = lane & 31 of row R
-    // holds logical 16-byte slot p ^ (R & 15)
-    const TailRound *__restrict__ rtab = a.rounds;
-    auto round_dma = [&](int r, int buf) {
-        const const_u32_ptr rp = (const_u32_ptr)(rtab + r);
-        const u32x8 e = *reinterpret_cast<const __attribute__((address_space(4))) u32x8 *>(rp);
-        const uint64_t src = ((uint64_t)e[1] << 32) | e[0];
-        const int row_bytes = (int)e[2], cbyte = (int)e[3], mode = (int)e[4], phase = (int)e[5], nsub = (int)e[6];
-        const int rows_src = mode == 0 ? M : (mode == 1 ? M >> 2 : M << 2);
-        const __amdgpu_buffer_rsrc_t rs = uniform_rsrc((const void *)src, rows_src * row_bytes);
-        const int py = phase >> 1, px = phase & 1;
-#pragma unroll
-        for (int i = 0; i < NDMA; ++i) {
-            const int R = (w * NDMA + i) * 2 + kh;
-            const int s = q ^ (R & 15);
-            const int m = m0 + R;
-            const int b = m >> hwlog, pix = m & (HW - 1), y = pix >> wlog, x = pix & (Wd - 1);
-            int srow = m;
-            if (mode == 1) srow = ((b << (hwlog - 2)) + ((y >> 1) << (wlog - 1))) + (x >> 1);
-            if (mode == 2) srow = ((((b * Hd + y) * 2 + py) << (wlog + 1)) + 2 * x + px);
-            const bool ok = m < M && s < nsub * 4;
-            const unsigned voff = ok ? (unsigned)(srow * row_bytes + cbyte + s * 16) : 0x80000000u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + buf * PB + (w * NDMA + i) * 1024), 16, voff, 0,
-                                                     0, 0);
-        }
-    };
-
-    const int nrounds = a.nrounds;
-    round_dma(0, 0);
+    mark(9);
 
     // ---- weight stream of this wave: fragments in consumption order, D steps ahead in registers ---------------------
-    const v8 *wp = reinterpret_cast<const v8 *>((const char *)a.wgt + (size_t)nt * a.tile_bytes + (size_t)w * a.wave_bytes) + l;
+    // Read through a buffer descriptor that ends behind the wave's last useful entry: the loads of the padding entries
+    // (the list is padded to a multiple of D, and the ring runs D entries ahead) fall outside and cost no traffic.
+    const int nuse = w == 0 ? a.nuse[0] : w == 1 ? a.nuse[1] : w == 2 ? a.nuse[2] : w == 3 ? a.nuse[3] : w == 4 ? a.nuse[4]
+                   : w == 5 ? a.nuse[5] : w == 6 ? a.nuse[6] : a.nuse[7];
+    const __amdgpu_buffer_rsrc_t wrs =
+        uniform_rsrc((const char *)a.wgt + (size_t)nt * a.tile_bytes + (size_t)w * a.wave_bytes, nuse * NL * 1024);
+    int wofs = 0;                                // byte offset of the next entry to request
+    auto wload = [&](int frag) {
+        return __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(wrs, l * 16 + frag * 1024, wofs, 0));
+    };
     v8 Wr[D][NL];
     // issued in ring order (the compiler's vmcnt bookkeeping at the loop head takes the minimum over the prologue and the
     // back edge: a reordered prologue would make every iteration drain the ring)
+    // Only the first half of the ring is requested in front of the first barrier: the first patch round shares the CU's
+    // 64 B/clk load path with whatever is requested next to it, and nothing can start before it has landed in every wave.
+    constexpr int DH = D / 2;
 #pragma unroll
-    for (int d = 0; d < D; ++d)
+    for (int d = 0; d < DH; ++d)
 #pragma unroll
         for (int f = 0; f < NL; ++f) {
-            Wr[d][f] = wp[(d * NL + f) * 64];
+            Wr[d][f] = wload(d * NL + f);
             asm volatile("" ::: "memory");
         }
-    wp += D * NL * 64;
-    // the second round's patch behind the first weights: the first MFMA waits for round 0 and one step of weights only
-    if (nrounds > 1) round_dma(1, 1);
+    mark(10);
 
     // ---- fragment address table: [slot 0..9][m-block][lane] -> byte offset of the lane's 16 bytes inside a patch
     // buffer for (sub-chunk 0, k16 slice 0); slot = 3 (dy + 1) + (dx + 1), slot 9 = zero row
@@ -230,17 +246,28 @@ __global__ __launch_bounds__(TS_NT) void conv_s(const TailArgs a) {
             for (int e = 0; e < 16; ++e) acc[n][i][e] = 0.f;
 
     mark(1);
-    // round 0 of the patch is older than the D * NL weight loads and the second round
-    if (nrounds > 1) wait_vm<D * NL + NDMA>();
-    else wait_vm<D * NL>();
+    // round 0 of the patch is older than the DH * NL weight loads
+    wait_vm<DH * NL>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    // second half of the ring, then the second round's patch (it is needed at the first round boundary)
+#pragma unroll
+    for (int d = DH; d < D; ++d)
+#pragma unroll
+        for (int f = 0; f < NL; ++f) {
+            Wr[d][f] = wload(d * NL + f);
+            asm volatile("" ::: "memory");
+        }
+    wofs = D * NL * 1024;
+    if (nrounds > 1) round_dma_desc((uint64_t)a.r1.src, a.r1.row_bytes, a.r1.cbyte, a.r1.mode, a.r1.phase, a.r1.nsub, 1);
+    mark(11);
 
     mark(2);
     // ---- main loop: this wave's step list ------------------------------------------------------------------------------
     // entry: [3:0] table slot, [6:4] 32-channel sub-chunk of the round, [7] patch buffer, [8] round boundary after this
-    // entry, [12:9] entries of this wave in the round (capped at D + 1).  The fragments of entry k + 1 are read while the
+    // entry, [12:9] entries of this wave in the round (capped at D + 1), [13] no work (padding of the list,
+    // or the placeholder of a wave without a step in a round: it only carries the boundary).  The fragments of entry k + 1 are read while the
     // MFMAs of entry k run (two register sets), except across a round boundary.
     const const_u32_ptr dp = (const_u32_ptr)a.desc + (size_t)w * a.maxsteps;
     const int *tab = reinterpret_cast<const int *>(smem + OFF_TAB) + l;
@@ -258,7 +285,7 @@ __global__ __launch_bounds__(TS_NT) void conv_s(const TailArgs a) {
 #pragma unroll
             for (int i = 0; i < NMB; ++i) f[ks][i] = *reinterpret_cast<const v8 *>(smem + ((ta[i] ^ (jx | (ks << 5))) + bufoff));
     };
-    read_frags(__builtin_amdgcn_readfirstlane(dnext[0]), fb[0]);
+    if (!(dnext[0] & 0x2000u)) read_frags(__builtin_amdgcn_readfirstlane(dnext[0]), fb[0]);
     for (int s0 = 0; s0 < a.maxsteps; s0 += D) {
         const u32xD dd = dnext;
         {
@@ -270,19 +297,22 @@ __global__ __launch_bounds__(TS_NT) void conv_s(const TailArgs a) {
             const uint32_t e = __builtin_amdgcn_readfirstlane(dd[d]);
             const uint32_t en = __builtin_amdgcn_readfirstlane(d + 1 < D ? dd[d + 1 < D ? d + 1 : 0] : dnext[0]);
             const bool boundary = (e & 0x100u) != 0;
-            if (!boundary) read_frags(en, fb[(d + 1) & 1]);
+            if (!boundary && !(en & 0x2000u)) read_frags(en, fb[(d + 1) & 1]);
+            if (!(e & 0x2000u)) {                        // (padding and placeholder entries: no LDS reads, no MFMAs)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int n = 0; n < NB; ++n)
+                    for (int n = 0; n < NB; ++n)
 #pragma unroll
-                    for (int i = 0; i < NMB; ++i) acc[n][i] = TT<T>::mfma(Wr[d][ks * NB + n], fb[d & 1][ks][i], acc[n][i]);
+                        for (int i = 0; i < NMB; ++i)
+                            acc[n][i] = TT<T>::mfma(Wr[d][ks * NB + n], fb[d & 1][ks][i], acc[n][i]);
+            }
 #pragma unroll
             for (int f = 0; f < NL; ++f) {
-                Wr[d][f] = wp[f * 64];
+                Wr[d][f] = wload(f);
                 asm volatile("" ::: "memory");
             }
-            wp += NL * 64;
+            wofs += NL * 1024;
             if (boundary) {
                 // round boundary: my pieces of the next round's patch have landed (they are older than the weights of
                 // the entries of this round), every wave is done with the current buffer -> refill it two rounds ahead
@@ -292,7 +322,7 @@ __global__ __launch_bounds__(TS_NT) void conv_s(const TailArgs a) {
                 asm volatile("" ::: "memory");
                 ++cur_round;
                 if (cur_round + 1 < nrounds) round_dma(cur_round + 1, (cur_round + 1) & 1);
-                read_frags(en, fb[(d + 1) & 1]);
+                if (!(en & 0x2000u)) read_frags(en, fb[(d + 1) & 1]);
             }
         }
     }
@@ -626,7 +656,8 @@ TailPlan build_tail_plan(const std::vector<TailSeg> &segs, int Cout_rows, int NB
                 lists[w].push_back(Ent{(uint32_t)(t.ts | (j << 4) | ((r & 1) << 7)), r, j, t.wt, true});
             }
         for (int w = 0; w < TS_NW; ++w) {
-            if (lists[w].size() == first[w]) lists[w].push_back(Ent{(uint32_t)(TS_ZSLOT | ((r & 1) << 7)), r, 0, 0, false});
+            if (lists[w].size() == first[w])
+                lists[w].push_back(Ent{(uint32_t)(TS_ZSLOT | ((r & 1) << 7) | 0x2000u), r, 0, 0, false});
             if (r + 1 < (int)rounds.size()) {
                 const int cnt = (int)std::min<size_t>(lists[w].size() - first[w], (size_t)D + 1);
                 lists[w].back().d |= 0x100u | ((uint32_t)cnt << 9);
@@ -634,18 +665,21 @@ TailPlan build_tail_plan(const std::vector<TailSeg> &segs, int Cout_rows, int NB
         }
     }
     size_t mx = 0;
-    for (int w = 0; w < TS_NW; ++w) mx = std::max(mx, lists[w].size());
+    for (int w = 0; w < TS_NW; ++w) {
+        mx = std::max(mx, lists[w].size());
+        p.nuse[w] = (int)lists[w].size();                 // every list ends with a real or a boundary entry
+    }
     p.maxsteps = (int)((mx + D - 1) / D) * D;
     for (int w = 0; w < TS_NW; ++w)
-        while ((int)lists[w].size() < p.maxsteps) lists[w].push_back(Ent{(uint32_t)TS_ZSLOT, 0, 0, 0, false});
+        while ((int)lists[w].size() < p.maxsteps) lists[w].push_back(Ent{(uint32_t)(TS_ZSLOT | 0x2000u), 0, 0, 0, false});
     p.desc.resize((size_t)TS_NW * p.maxsteps);
     for (int w = 0; w < TS_NW; ++w)
         for (int s = 0; s < p.maxsteps; ++s) p.desc[(size_t)w * p.maxsteps + s] = lists[w][s].d;
 
-    // weight stream: [n-tile][wave][entry (+ D trailing dummies)][fragment ks * NB + nb][lane][8]
+    // weight stream: [n-tile][wave][entry][fragment ks * NB + nb][lane][8]
     const int NL = 2 * NB, TN = NB * 32, ntn = (Cout_rows + TN - 1) / TN;
     p.ntn = ntn;
-    p.wave_elems = (size_t)(p.maxsteps + D) * NL * 512;
+    p.wave_elems = (size_t)p.maxsteps * NL * 512;
     p.tile_elems = p.wave_elems * TS_NW;
     p.wgt.assign(p.tile_elems * ntn, 0.f);
     for (int nt = 0; nt < ntn; ++nt)

@@ -84,12 +84,19 @@ def _iadb_loop(model, x0, x_c, nb_step, scheduler_alpha, scheduler_gamma, schedu
         h = core._ensure_engine(B, x.shape[-1], x.device)
         xc = x_c.detach().to(torch.float32).contiguous() if x_c is not None else None
         dgz = dg if use_gamma else np.zeros_like(dg)
-        t0 = time.time()
+        # mean_forward_time: the reference brackets model(...) with time.time() WITHOUT a device synchronise
+        # (iadb_bn.py:318-321), i.e. it reports launch time.  Here the whole loop is one asynchronous C call, so the
+        # figure is taken from device events around it: (loop time) / steps, forward + Euler update, in seconds.
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         rc = lib.bndm_unet_sample_iadb(h, _ptr(x), _ptr(xc), B, Cc, nb_step, t_in.ctypes.data_as(C.c_void_p),
                                        da.ctypes.data_as(C.c_void_p), dgz.ctypes.data_as(C.c_void_p),
                                        mask.ctypes.data_as(C.c_void_p), _ptr(snaps), _lib.current_stream_ptr())
         _lib.check(rc, "bndm_unet_sample_iadb")
-        times = [(time.time() - t0) / max(nb_step, 1)] * 2
+        e1.record()
+        if train_or_test == "test":                     # only the 'test' form returns the figure (utils.py:237-240)
+            e1.synchronize()
+            times = [e0.elapsed_time(e1) * 1e-3 / max(nb_step, 1)] * 2
     else:
         k = 0
         for s in range(nb_step):

@@ -11,7 +11,7 @@ if "--match" in sys.argv:
 
 
 def family(name):
-    m = re.search(r"(conv_t32|conv_tap9s|conv_tap9|conv_fused|conv_igemm|conv_lowres|gn_small|gn_finalize2|gn_stats|gn_apply|"
+    m = re.search(r"(conv_t32|conv_s|conv_tap9s|conv_tap9|conv_fused|conv_igemm|conv_lowres|gn_small|gn_finalize2|gn_stats|gn_apply|"
                   r"attention|bluenoise_gemm|bluenoise_finish|conv_in|splitk_reduce|temb_mlp|conv_out|attn_block)", name)
     fam = m.group(1) if m else name[:40]
     t = re.search(r"Li(16|8)ELi\d+E", name)

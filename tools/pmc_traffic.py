@@ -15,7 +15,7 @@ LIB = os.path.join(ROOT, "bndm_amd", "libbndm_hip.so")
 
 
 def family(name):
-    m = re.search(r"(conv_t32|conv_igemm|gn_small|bluenoise_small|bluenoise_gemm)", name)
+    m = re.search(r"(conv_t32|conv_s|conv_igemm|gn_small|bluenoise_small|bluenoise_gemm)", name)
     if not m:
         return None
     fam = m.group(1)

@@ -38,6 +38,8 @@ static void run(const Case &c) {
     CK(hipMalloc(&dbg, 32 * 8)); CK(hipMemset(dbg, 0, 32 * 8));
     TailArgs a{};
     a.desc = (const uint32_t *)desc; a.rounds = (const TailRound *)rounds; a.nrounds = plan.nrounds; a.maxsteps = plan.maxsteps;
+    a.r0 = rt[0]; if (plan.nrounds > 1) a.r1 = rt[1];
+    for (int i = 0; i < 8; ++i) a.nuse[i] = plan.nuse[i];
     a.tile_bytes = (long long)plan.tile_elems * 2; a.wave_bytes = (int)(plan.wave_elems * 2);
     a.B = c.B; a.hwlog = 31 - __builtin_clz(HW); a.wlog = 31 - __builtin_clz(c.H); a.Cout = c.Cout; a.ntn = c.Cout / 32;
     a.bias = gamma; a.eps = 1e-5f; a.epi = c.qkv ? TAIL_EPI_ATTN : TAIL_EPI_CONV;
@@ -73,7 +75,9 @@ static void run(const Case &c) {
     for (int wv = 0; wv < 2; ++wv) {
         printf("    marks wave %d (clk since start): ", wv ? 7 : 0);
         for (int k = 1; k < 8; ++k) printf(" %6lld", h[16 * wv + k] ? (long long)(h[16 * wv + k] - h[0]) : -1LL);
-        printf("   [issue | landed+barrier | loop | drain | reduce | items | norm]\n");
+        printf("   [issue | landed+barrier | loop | drain | reduce | items | norm]   prologue:");
+        for (int k = 8; k < 12; ++k) printf(" %5lld", h[16 * wv + k] ? (long long)(h[16 * wv + k] - h[0]) : -1LL);
+        printf(" [rows req | dma0 | weights | dma1]\n");
     }
     CK(hipFree(W)); CK(hipFree(A1)); if (A2) CK(hipFree(A2)); CK(hipFree(out)); CK(hipFree(n1)); CK(hipFree(n2)); CK(hipFree(gamma));
     CK(hipFree(desc)); CK(hipFree(rounds)); CK(hipFree(dbg));
