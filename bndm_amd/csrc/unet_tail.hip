@@ -96,28 +96,16 @@ __global__ __launch_bounds__(TS_NT) void conv_s(const TailArgs a) {
     const int q = l & 31, kh = l >> 5;
     // profiling aid (tools/ubench/tail_bench): s_memtime marks of waves 0 and 7 of workgroup 0
     auto mark = [&](int k) {
-        if (a.dbg && blockIdx.x == 0 && (w == 0 || w == 7)) {
+        if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && (w == 0 || w == 7)) {
             const unsigned long long tm = __builtin_amdgcn_s_memtime();
             if (l == 0) a.dbg[(w ? 16 : 0) + k] = tm;
         }
     };
     mark(0);
 
-    // ---- tile id: workgroups of one n-tile (same weights) share an XCD / L2 ---------------------------------------
-    int mt, nt;
-    {
-        const int bid = blockIdx.x;
-        if ((a.ntn & 7) == 0) {
-            const int per = a.ntn >> 3, idx = bid >> 3;
-            nt = (bid & 7) + 8 * (idx % per);
-            mt = idx / per;
-        } else {
-            nt = bid % a.ntn;
-            mt = bid / a.ntn;
-        }
-    }
-    mt = __builtin_amdgcn_readfirstlane(mt);
-    nt = __builtin_amdgcn_readfirstlane(nt);
+    // ---- tile id: grid (n-tiles, m-tiles).  Workgroups are dealt to the 8 XCDs in linear order, so with a multiple of 8
+    // n-tiles every workgroup of an n-tile (same weights) lands on the same XCD / L2
+    const int nt = blockIdx.x, mt = blockIdx.y;
     const int hwlog = a.hwlog, wlog = a.wlog, HW = 1 << hwlog, Wd = 1 << wlog, Hd = HW >> wlog;
     const int M = a.B << hwlog;
     const int m0 = mt * TM;
@@ -132,15 +120,28 @@ __global__ __launch_bounds__(TS_NT) void conv_s(const TailArgs a) {
         const int rows_src = mode == 0 ? M : (mode == 1 ? M >> 2 : M << 2);
         const __amdgpu_buffer_rsrc_t rs = uniform_rsrc((const void *)src, rows_src * row_bytes);
         const int py = phase >> 1, px = phase & 1;
+        if (mode == 0) {                                 // same resolution: the tile's rows are consecutive source rows
+            const int R0 = w * NDMA * 2 + kh;
+            int rowoff = (m0 + R0) * row_bytes + cbyte;
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i) {
+                const int R = R0 + 2 * i, s = q ^ (R & 15);
+                const bool ok = m0 + R < M && s < nsub * 4;
+                const unsigned voff = ok ? (unsigned)(rowoff + s * 16) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + buf * PB + (w * NDMA + i) * 1024), 16, voff,
+                                                         0, 0, 0);
+                rowoff += 2 * row_bytes;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
             const int R = (w * NDMA + i) * 2 + kh;
             const int s = q ^ (R & 15);
             const int m = m0 + R;
             const int b = m >> hwlog, pix = m & (HW - 1), y = pix >> wlog, x = pix & (Wd - 1);
-            int srow = m;
-            if (mode == 1) srow = ((b << (hwlog - 2)) + ((y >> 1) << (wlog - 1))) + (x >> 1);
-            if (mode == 2) srow = ((((b * Hd + y) * 2 + py) << (wlog + 1)) + 2 * x + px);
+            const int srow = mode == 1 ? ((b << (hwlog - 2)) + ((y >> 1) << (wlog - 1))) + (x >> 1)
+                                       : ((((b * Hd + y) * 2 + py) << (wlog + 1)) + 2 * x + px);
             const bool ok = m < M && s < nsub * 4;
             const unsigned voff = ok ? (unsigned)(srow * row_bytes + cbyte + s * 16) : 0x80000000u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + buf * PB + (w * NDMA + i) * 1024), 16, voff, 0,
@@ -574,7 +575,7 @@ template <typename T, int TM, int NB, int D> int launch_tail_t(const TailArgs &a
         attr = true;
     }
     const int M = a.B << a.hwlog, ntm = (M + TM - 1) / TM;
-    hipLaunchKernelGGL((conv_s<T, TM, NB, D>), dim3(ntm * a.ntn), dim3(TS_NT), smem, st, a);
+    hipLaunchKernelGGL((conv_s<T, TM, NB, D>), dim3(a.ntn, ntm), dim3(TS_NT), smem, st, a);
     return launch_status("conv_s");
 }
 
