@@ -485,8 +485,15 @@ __global__ __launch_bounds__(TS_NT) void conv_s(const TailArgs a) {
             x = dpp_add(x, IC<0x124>{});                       // row_ror:4, row_ror:8: the four lanes = l (mod 4) of a row
             x = dpp_add(x, IC<0x128>{});
             if (hwlog >= 4) {
-                x += __shfl_xor(x, 16);
-                x += __shfl_xor(x, 32);
+                // rows 0+1 / 2+3, then the two halves: v_permlane16_swap / v_permlane32_swap exchange rows between two
+                // registers holding the same value (written as instructions: the builtin's two results were folded into
+                // one by the compiler)
+                unsigned a = __builtin_bit_cast(unsigned, x), b;
+                asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "=&v"(b));
+                x = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+                a = __builtin_bit_cast(unsigned, x);
+                asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "=&v"(b));
+                x = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
             }
             return x;
         };
