@@ -12,7 +12,7 @@ if [ ! -f $R/tools/libbndm_ablate.so ] || [ "$1" = "--build" ]; then
   [ "$1" = "--build" ] && exit 0
 fi
 cd $R; mkdir -p gpurun_out
-for a in ${@:-0 15}; do
+for a in ${@:-0 15}; do  # (BNDM_ABLATE_NW8=1 in the environment forces the 8-wave variant)
   BNDM_ABLATE=$a BNDM_T32_TRACE=gpurun_out/t32_trace_$a.txt BNDM_PROFILE_DUMP=gpurun_out/abl_$a.txt python tools/ablate_run.py > /dev/null 2>&1
   echo "ABL=$a: d0.conv1 (K=1152): $(grep 'down_blocks.0.resnets.0.conv1' gpurun_out/abl_$a.txt | awk '{print $2}')  up5.conv1 (K=2304): $(grep 'up_blocks.5.resnets.0.conv1 ' gpurun_out/abl_$a.txt | awk '{print $2}')  up4.ups: $(grep 'up_blocks.4.upsamplers' gpurun_out/abl_$a.txt | awk '{print $2}') d1.conv1(32x32): $(grep 'down_blocks.1.resnets.0.conv1' gpurun_out/abl_$a.txt | awk '{print $2}')"
 done

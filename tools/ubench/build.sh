@@ -5,3 +5,4 @@ hipcc -O3 --offload-arch=gfx950 dma_rate.hip -o dma_rate.bin -w
 hipcc -O3 --offload-arch=gfx950 -std=c++17 -w igemm_bench.cpp -o igemm_bench.bin -L../../bndm_amd -lbndm_hip -Wl,-rpath,'$ORIGIN/../../bndm_amd'
 hipcc -O3 --offload-arch=gfx950 -std=c++17 -w noise_bench.cpp -o noise_bench.bin -L../../bndm_amd -lbndm_hip -Wl,-rpath,'$ORIGIN/../../bndm_amd'
 hipcc -O3 --offload-arch=gfx950 -std=c++17 -w tail_bench.cpp -o tail_bench.bin -L../../bndm_amd -lbndm_hip -Wl,-rpath,'$ORIGIN/../../bndm_amd'
+hipcc -O3 --offload-arch=gfx950 -w covalu.hip -o covalu.bin
