@@ -77,8 +77,11 @@ struct Chunk {
 // NCO: output channels per workgroup.  128: the ResnetBlock2D / Upsample2D convolutions (16-bit NHWC output + GroupNorm
 // partial sums).  32: the network head -- conv_norm_out + SiLU + conv_out (iadb_bn.py:205-282: out_channels 3 / 6 / 8),
 // written as the caller's fp32 NCHW tensor; the loop is then bound by the one read + normalisation of the input.
-template <typename T, int TH, int ABL, int NW, int NCO>
-__global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const int tiles_x, const int tps, const int ntn,
+// SS: super-step schedule of the 8-wave variant (one workgroup per CU): one barrier per THREE taps, a weight ring of nine
+// tiles (= one chunk: tap t lives in slot t) filled two super-steps ahead, three patch buffers (the chunk after next is
+// DMA'd while the next one is normalised).  Same MFMA order as the per-tap schedule, i.e. bit-identical results.
+template <typename T, int TH, int ABL, int NW, int NCO, int SS = 0>
+__global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs a, const int tiles_x, const int tps, const int ntn,
                                                    const int nsteps_w, unsigned *__restrict__ dbg) {
     using v8 = typename TT<T>::v8;
     using v4 = typename TT<T>::v4;
@@ -95,8 +98,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
     constexpr int TM = TH / 8;                         // 32-pixel MFMA tiles per wave along M (2 rows x 16 columns each)
     constexpr int TN = NCO / 32 / WAVES_N;             // 32-channel MFMA tiles per wave along N
     static_assert(TN >= 1, "wave tiling");
-    constexpr int WSTAGES = 4, W_BYTES = NCO * 64;
-    constexpr int OFF_W = 2 * PATCH_BYTES;
+    static_assert(!SS || (NW == 8 && NCO == 128), "super-steps: 8-wave, 128-channel variant only");
+    constexpr int WSTAGES = SS ? 9 : 4, W_BYTES = NCO * 64, NPB = SS ? 3 : 2;
+    constexpr int OFF_W = NPB * PATCH_BYTES;
     constexpr int OFF_SS = OFF_W + WSTAGES * W_BYTES;
     constexpr int OFF_TAB = OFF_SS + T32_SS_BYTES;     // chunk descriptors, 16 B each
     constexpr int OFF_BIAS = OFF_TAB + T32_MAX_CHUNKS * 16;   // 128 fp32: bias (+ time embedding) row of this tile
@@ -297,10 +301,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
         for (int j = 0; j < TM; ++j)
             fb[ks][j] = *reinterpret_cast<const v8 *>(smem + pb + ((ky & 2) * PW + 2 * j * PW) * 64);
     };
-    auto read_a = [&](auto kc, int i) {
-        constexpr int ks = decltype(kc)::value;
+    auto read_a = [&](auto tc, auto kc, int i) {     // (SS: tap t of a chunk lives in ring slot t)
+        constexpr int ks = decltype(kc)::value, t = decltype(tc)::value;
         if (ABL & 4) return;
-        fa[i] = *reinterpret_cast<const v8 *>(smem + (wa ^ (ks << 5)) + i * 2048);
+        fa[i] = *reinterpret_cast<const v8 *>(smem + (wa ^ (ks << 5)) + i * 2048 + (SS ? t * W_BYTES : 0));
     };
     // one phase: the MFMAs of k16 slice `kcur` (operands in fa, fb[kcur]) and the reads of slice (tnext, knext)
     auto mma_refill = [&](auto kcur, auto tnext, auto knext) {
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
 #pragma unroll
                 for (int j = 0; j < TM; ++j) acc[i][j] = TT<T>::mfma(fa[i], fb[ks][j], acc[i][j]);
             }
-            read_a(knext, i);
+            read_a(tnext, knext, i);
         }
     };
 
@@ -326,6 +330,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // chunk table visible
     asm volatile("" ::: "memory");
+    life(6);
     Chunk cur = load_chunk(0);
     Chunk nxt = cur;
     {
@@ -354,15 +359,33 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
             }
         };
         issue_all(issue_all, IC<0>{});
-        w_issue(0, 0);
-        w_issue(1, 1);
-        w_issue(2, 2);
-        w_issue(3, 3);
+        if constexpr (SS) {
+            // group 1: patch of chunk 0 (above), tiles 0..2, round 0 of chunk 1; groups 2 and 3 have the shape of the
+            // main loop's DMA batches (one patch round, three tiles), so that its counted waits hold from the first barrier
+            nxt = load_chunk(nchunk9 > 1 ? 1 : 0);
+            auto tile = [&](int t) { w_issue(t, t < nstep9 ? t : nstep9 - 1); };
+            auto round = [&](auto rc) {
+                if constexpr (decltype(rc)::value < NROUND) patch_dma(rc, nxt, 1);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(smem + OFF_DUMP), 16, 0x80000000u, 0, 0, 0);
+            };
+            tile(0), tile(1), tile(2);
+            round(IC<0>{});
+            round(IC<1>{});
+            tile(3), tile(4), tile(5);
+            round(IC<2>{});
+            tile(6), tile(7), tile(8);
+        } else {
+            w_issue(0, 0);
+            w_issue(1, 1);
+            w_issue(2, 2);
+            w_issue(3, 3);
+        }
+        life(7);
         if (a.gn_p1) {
             // GroupNorm(32) statistics of cat(x1, x2) for this sample from the producers' per-tile partial sums (fixed slab
             // order, fp64 group combine: the arithmetic of gn_finalize2), while the DMAs above are in flight.  Scratch: the
             // second patch buffer, idle until the main loop.
-            float *cs = reinterpret_cast<float *>(smem + PATCH_BYTES), *css = cs + 512;
+            float *cs = reinterpret_cast<float *>(smem + (NPB - 1) * PATCH_BYTES), *css = cs + 512;
             const int C = a.ssC, C1 = a.gn_C1;
             float gam[2], bet[2];                        // C <= 512: at most two channels per thread; loaded up front
 #pragma unroll
@@ -394,6 +417,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            life(8);
             const int Cg = C >> 5;
             float *ssW = reinterpret_cast<float *>(smem + OFF_SS);
 #pragma unroll
@@ -416,9 +440,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
                 ssW[C + c] = bet[k2] - (float)mean * sc;
             }
         }
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * NWP) : "memory");   // table + own patch pieces landed
+        life(9);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(SS ? 8 : 4 * NWP) : "memory");   // table + own patch pieces landed
         __builtin_amdgcn_s_barrier();                         // ... in every wave (the table is shared)
         asm volatile("" ::: "memory");
+        life(10);
         if (!(ABL & 8) && cur.ssbase >= 0) {
             auto xf_all = [&](auto self, auto rc) {
                 constexpr int r = decltype(rc)::value;
@@ -436,7 +462,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
             xf_all(xf_all, IC<0>{});
         }
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    life(11);
+    if constexpr (SS) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");    // (tiles 0..2 of every thread)
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (nchunk9 > 1) nxt = load_chunk(1);
@@ -461,7 +489,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
     if (nchunk9 > 0) {
         read_b(IC<0>{}, IC<0>{});
 #pragma unroll
-        for (int i = 0; i < TN; ++i) read_a(IC<0>{}, i);
+        for (int i = 0; i < TN; ++i) read_a(IC<0>{}, IC<0>{}, i);
     }
     constexpr int NFULL = NROUND - (NREMW < NW ? 1 : 0);   // rounds in which every wave owns pieces
     static_assert(NFULL <= 5, "normalisation schedule: one full round per window of steps 3..7 (+ a partial one)");
@@ -606,13 +634,137 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
         step(IC<7>{});
         step(IC<8>{});
     };
+    // ---- super-step schedule (SS) ---------------------------------------------------------------------------
+    // Steps as above, but the barrier (between the two phases of a step) only at taps 2, 5, 8: B(c, j).  All reads of the
+    // tiles of taps <= 3j+2 are issued before it, so behind it the DMA batch
+    //     [ patch round j of chunk c+2 -> buffer (c+2) % 3,  weight tiles 9c + 3j + 9 .. +2 -> slots 3j .. 3j+2 ]
+    // may go out: four DMAs per thread, always (a dummy stands in for a missing round).  The wait before B(k) lets the
+    // four DMAs of batch k-1 stay in flight, i.e. certifies batch k-2: the tiles of the next super-step (two super-steps
+    // to land) and a patch round of the next chunk, which its issuing thread normalises in place behind B(k) (round j
+    // in the second phase of step 3j and the first phase of step 3j+1, before B(c, j)); B(c, 2) publishes the chunk.
+    int b1 = 1, b2 = 2;                                  // patch buffers of chunks c+1, c+2
+    Chunk nx2 = cur;
+    if constexpr (SS) nx2 = load_chunk(nchunk9 > 2 ? 2 : nchunk9 - 1 > 0 ? nchunk9 - 1 : 0);
+    auto chunk_body_ss = [&](auto doxc, const int c) __attribute__((always_inline)) {
+        constexpr bool DOX = decltype(doxc)::value != 0 && !(ABL & 8);
+        u32x4 xa = {0u, 0u, 0u, 0u};
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, ha = {0.f, 0.f, 0.f, 0.f};
+        auto mark = [&](int t, int k) {
+            if constexpr ((ABL & 64) != 0) {
+                if (blockIdx.x == 0 && c == 1 && w < 4) {
+                    const unsigned tm = (unsigned)__builtin_amdgcn_s_memtime();
+                    if (l == 0) dbg[(w * 9 + t) * 6 + k] = tm;
+                }
+            }
+        };
+        auto xs_pre = [&](auto sc, auto pc) {
+            constexpr int s = decltype(sc)::value, p = decltype(pc)::value;
+            constexpr int r = s >= 0 && s % 3 == 0 && s / 3 < NROUND ? s / 3 : -1;
+            if constexpr (DOX && r >= 0) {
+                if (xf_owner(r)) {
+                    if constexpr (p == 0) xf_begin(IC<r>{}, b1, xa);
+                    const float *sc4 = ssL + nxt.ssbase + piece_of(r).lc * 8 + 4 * p;
+                    sa = *reinterpret_cast<const f32x4 *>(sc4);
+                    ha = *reinterpret_cast<const f32x4 *>(sc4 + a.ssC);
+                }
+            }
+        };
+        auto xs_math = [&](auto sc, auto pc) {
+            constexpr int s = decltype(sc)::value, p = decltype(pc)::value;
+            constexpr int r = s >= 0 && s % 3 == 0 && s / 3 < NROUND ? s / 3 : -1;
+            if constexpr (DOX && r >= 0) {
+                if (xf_owner(r)) {
+                    const bool valid = piece_of(r).valid;
+                    xa[2 * p] = norm2(xa[2 * p], sa[0], sa[1], ha[0], ha[1], valid);
+                    xa[2 * p + 1] = norm2(xa[2 * p + 1], sa[2], sa[3], ha[2], ha[3], valid);
+                    if constexpr (p == 1) xf_end(IC<r>{}, b1, xa);
+                }
+            }
+        };
+        auto phase = [&](auto kcur, auto tnext, auto knext, auto sc, auto pc, auto nvm) {
+            constexpr int s = decltype(sc)::value, NVMEM = decltype(nvm)::value;
+            constexpr int r = s >= 0 && s % 3 == 0 && s / 3 < NROUND ? s / 3 : -1;
+            __builtin_amdgcn_sched_barrier(0);
+            mma_refill(kcur, tnext, knext);
+            xs_math(sc, pc);
+            constexpr int NV = DOX && r >= 0 ? 11 : 2;
+            __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (2 * i < NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);               // (NVMEM is 0 or 4)
+                __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto step = [&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            mark(t, 0);
+            phase(IC<0>{}, tc, IC<1>{}, IC<t - 1>{}, IC<1>{}, IC<0>{});
+            xs_pre(tc, IC<0>{});
+            mark(t, 1);
+            if constexpr (t % 3 == 2) {
+                constexpr int j = t / 3;
+                if constexpr (t == 8) {                       // the next chunk's patch, for the reads behind the barrier
+                    const int d = c % 3 == 2 ? -2 * PATCH_BYTES : PATCH_BYTES;
+#pragma unroll
+                    for (int kyp = 0; kyp < 2; ++kyp)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) pa[kyp][kx] += d;
+                }
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(1 + 3 * NWP) : "memory");
+                mark(t, 2);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                mark(t, 3);
+                if constexpr (j < NROUND && !(ABL & 8)) patch_dma(IC<(j < NROUND ? j : 0)>{}, nx2, b2);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(smem + OFF_DUMP), 16, 0x80000000u, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int ws = 9 * c + 3 * j + 9 + i;
+                    if (!(ABL & 2)) w_issue(3 * j + i, ws < nstep9 ? ws : nstep9 - 1);
+                }
+                if constexpr (t == 8) {
+                    const int b0 = b1;
+                    b1 = b2;
+                    b2 = b0 == 0 ? 2 : b0 - 1;               // (c+3) % 3 = c % 3: the buffer the finished chunk leaves
+                    nxt = nx2;
+                    nx2 = load_chunk(c + 3 < nchunk9 ? c + 3 : nchunk9 - 1);
+                }
+                phase(IC<1>{}, IC<(t + 1) % 9>{}, IC<0>{}, tc, IC<0>{}, IC<1 + 3 * NWP>{});
+            } else {
+                phase(IC<1>{}, IC<(t + 1) % 9>{}, IC<0>{}, tc, IC<0>{}, IC<0>{});
+            }
+            xs_pre(tc, IC<1>{});
+            mark(t, 4);
+        };
+        step(IC<0>{});
+        step(IC<1>{});
+        step(IC<2>{});
+        step(IC<3>{});
+        step(IC<4>{});
+        step(IC<5>{});
+        step(IC<6>{});
+        step(IC<7>{});
+        step(IC<8>{});
+    };
     if (nchunk9 > 0) {
-        if (cur.ssbase >= 0) {
-            for (int c = 0; c + 1 < nchunk9; ++c) chunk_body(IC<1>{}, c);
+        if constexpr (SS) {
+            if (cur.ssbase >= 0) {
+                for (int c = 0; c + 1 < nchunk9; ++c) chunk_body_ss(IC<1>{}, c);
+            } else {
+                for (int c = 0; c + 1 < nchunk9; ++c) chunk_body_ss(IC<0>{}, c);
+            }
+            chunk_body_ss(IC<0>{}, nchunk9 - 1);
         } else {
-            for (int c = 0; c + 1 < nchunk9; ++c) chunk_body(IC<0>{}, c);
+            if (cur.ssbase >= 0) {
+                for (int c = 0; c + 1 < nchunk9; ++c) chunk_body(IC<1>{}, c);
+            } else {
+                for (int c = 0; c + 1 < nchunk9; ++c) chunk_body(IC<0>{}, c);
+            }
+            chunk_body(IC<0>{}, nchunk9 - 1);
         }
-        chunk_body(IC<0>{}, nchunk9 - 1);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -775,23 +927,24 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_t32(const FusedArgs a, const 
     life(5);
 }
 
-template <int TH, int NW, int NCO = 128> constexpr int t32_smem_bytes() {
+template <int TH, int NW, int NCO = 128, int SS = 0> constexpr int t32_smem_bytes() {
     constexpr int NT = NW * 64;
     constexpr int NPIECE = (TH + 2) * 18 * 4, NROUND = (NPIECE + NT - 1) / NT;
     constexpr int NREMW = (NPIECE - (NROUND - 1) * NT + 63) / 64;
     constexpr int PATCH_BYTES = (NROUND - 1) * NT * 16 + NREMW * 1024;
-    constexpr int main_bytes = 2 * PATCH_BYTES + 4 * NCO * 64 + T32_SS_BYTES + T32_MAX_CHUNKS * 16 + 512 + 1024;
+    constexpr int main_bytes =
+        (SS ? 3 : 2) * PATCH_BYTES + (SS ? 9 : 4) * NCO * 64 + T32_SS_BYTES + T32_MAX_CHUNKS * 16 + 512 + 1024;
     constexpr int epi_bytes = NCO >= 64 ? TH * 16 * NCO * 2 + NW * NCO * 2 * 4 : 0;
     return main_bytes > epi_bytes ? main_bytes : epi_bytes;
 }
 
-template <typename T, int TH, int ABL, int NW = 4, int NCO = 128>
+template <typename T, int TH, int ABL, int NW = 4, int NCO = 128, int SS = 0>
 int launch_t32_t(const FusedArgs &a, hipStream_t st) {
-    constexpr int smem = t32_smem_bytes<TH, NW, NCO>();
-    static_assert(smem <= 80 * 1024, "LDS budget: two workgroups per CU");
+    constexpr int smem = t32_smem_bytes<TH, NW, NCO, SS>();
+    static_assert(smem <= (SS ? 160 : 80) * 1024, "LDS budget: two workgroups per CU (one with super-steps)");
     static bool attr = false;
     if (!attr) {
-        BNDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_t32<T, TH, ABL, NW, NCO>),
+        BNDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_t32<T, TH, ABL, NW, NCO, SS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr = true;
     }
@@ -805,7 +958,7 @@ int launch_t32_t(const FusedArgs &a, hipStream_t st) {
         if (!buf) BNDM_CHECK_HIP(hipMalloc(&buf, (4 * 9 * 6 + 32) * sizeof(unsigned)));
         dbg = buf;
     }
-    hipLaunchKernelGGL((conv_t32<T, TH, ABL, NW, NCO>), grid, dim3(NW * 64), smem, st, a, tiles_x, tps, ntn, nsteps, dbg);
+    hipLaunchKernelGGL((conv_t32<T, TH, ABL, NW, NCO, SS>), grid, dim3(NW * 64), smem, st, a, tiles_x, tps, ntn, nsteps, dbg);
 #ifdef BNDM_ABLATION      // profiling builds only (tools/ablate.sh)
 #include "ablation_t32_trace.inc"
 #endif
@@ -880,10 +1033,11 @@ int launch_conv_t32(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
 #ifdef BNDM_ABLATION      // profiling builds only (tools/ablate.sh)
 #include "ablation_t32_dispatch.inc"
 #endif
-        if (nw == 8) return TH == 16 ? launch_t32_t<_Float16, 16, 0, 8>(a, st) : launch_t32_t<_Float16, 8, 0, 8>(a, st);
+        if (nw == 8)
+            return TH == 16 ? launch_t32_t<_Float16, 16, 0, 8, 128, 1>(a, st) : launch_t32_t<_Float16, 8, 0, 8, 128, 1>(a, st);
         return TH == 16 ? launch_t32_t<_Float16, 16, 0>(a, st) : launch_t32_t<_Float16, 8, 0>(a, st);
     }
-    if (nw == 8) return TH == 16 ? launch_t32_t<__bf16, 16, 0, 8>(a, st) : launch_t32_t<__bf16, 8, 0, 8>(a, st);
+    if (nw == 8) return TH == 16 ? launch_t32_t<__bf16, 16, 0, 8, 128, 1>(a, st) : launch_t32_t<__bf16, 8, 0, 8, 128, 1>(a, st);
     return TH == 16 ? launch_t32_t<__bf16, 16, 0>(a, st) : launch_t32_t<__bf16, 8, 0>(a, st);
 }
 
