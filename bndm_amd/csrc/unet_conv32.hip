@@ -145,28 +145,29 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
             else nchunk1 += a.seg[i].C >> 5;
         }
     if (tid < nchunk9 + nchunk1) {
-        int rem = tid, si = 0, ci = 0;
+        // every segment's fields as SCALARS first, then per-lane selects of values: a select between the kernel-argument
+        // structs themselves becomes a vector load through a selected pointer, i.e. a cold global round trip at the head
+        // of every launch
+        int rem = tid;
         bool found = false;
+        u32x4t e = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < CONV_MAX_SEG; ++i) {
-            const int nci = i < a.nseg ? a.seg[i].C >> 5 : 0;
-            if (!found && rem < nci) {
-                si = i;
-                ci = rem;
-                found = true;
-            }
+            const bool on = i < a.nseg;
+            const uint64_t u = (uint64_t)a.seg[i].src;
+            const uint32_t ulo = __builtin_amdgcn_readfirstlane((uint32_t)u), uhi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+            const int Ci = __builtin_amdgcn_readfirstlane(on ? a.seg[i].C : 0);
+            const uint32_t upi = __builtin_amdgcn_readfirstlane((uint32_t)a.seg[i].up);
+            const int ssi = __builtin_amdgcn_readfirstlane(a.seg[i].ss_off);
+            const int nci = Ci >> 5;
+            const bool hit = !found && rem < nci;
+            e[0] = hit ? ulo : e[0];
+            e[1] = hit ? uhi : e[1];
+            e[2] = hit ? (uint32_t)(Ci * 2) | ((uint32_t)(rem * 64) << 12) | (upi << 31) : e[2];
+            e[3] = hit ? (uint32_t)(ssi >= 0 ? ssi + rem * 32 : -1) : e[3];
+            found = found || hit;
             rem -= nci;
         }
-        FusedSeg sg = a.seg[0];
-        if (si == 1) sg = a.seg[1];
-        if (si == 2) sg = a.seg[2];
-        if (si == 3) sg = a.seg[3];
-        const uint64_t u = (uint64_t)sg.src;
-        u32x4t e;
-        e[0] = (uint32_t)u;
-        e[1] = (uint32_t)(u >> 32);
-        e[2] = (uint32_t)(sg.C * 2) | ((uint32_t)(ci * 64) << 12) | ((uint32_t)sg.up << 31);
-        e[3] = (uint32_t)(sg.ss_off >= 0 ? sg.ss_off + ci * 32 : -1);
         *reinterpret_cast<u32x4t *>(smem + OFF_TAB + tid * 16) = e;
     }
     auto load_chunk = [&](int n) {
