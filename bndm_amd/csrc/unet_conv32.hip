@@ -134,7 +134,6 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
     const int y0 = __builtin_amdgcn_readfirstlane(ty * TH), x0 = __builtin_amdgcn_readfirstlane(tx * TW);
     const int n0 = __builtin_amdgcn_readfirstlane(nt * NCO);
     const int H = a.H, Wd = a.W;
-    const int lgH = 31 - __builtin_clz(H), lgW = 31 - __builtin_clz(Wd);
 
     // ---- chunk descriptors of the whole K loop (3x3 chunks first, then the 1x1 ones), built once into LDS ----------
     int nchunk9 = 0, nchunk1 = 0;           // 3x3 segments come first (checked by the launcher)
@@ -187,6 +186,7 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
     // ---- patch piece descriptors (independent of the chunk) ----------------------------------------
     // piece = round * 256 + tid = (patch pixel, physical 16-byte slot); slot j of pixel (py, px) holds channel group
     // j ^ key(py, px)
+    const bool src_up = a.seg[0].up != 0;              // nearest-2x sources: all segments of a launch or none (conv_t32_supports)
     int p_full[NROUND];                                // source pixel index of the piece, -1: padding
     int p_pack = 0;                                    // per round: bits 3r, 3r+1 source channel group, bit 3r+2 valid
 #pragma unroll
@@ -197,7 +197,9 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
         const int pyy = pp / PW, pxx = pp - pyy * PW;
         const int iy = y0 - 1 + pyy, ix = x0 - 1 + pxx;
         const bool ok = piece < NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)Wd;
-        p_full[r] = ok ? (b * H + iy) * Wd + ix : -1;                      // -1: out-of-range offset -> zeros
+        // (a half-resolution source is indexed at its own resolution here, once, instead of per chunk in the K loop)
+        const int pix = src_up ? (b * (H >> 1) + (iy >> 1)) * (Wd >> 1) + (ix >> 1) : (b * H + iy) * Wd + ix;
+        p_full[r] = ok ? pix : -1;                                         // -1: out-of-range offset -> zeros
         p_pack |= ((pch ^ t32_patch_key(pyy, pxx)) | (ok ? 4 : 0)) << (3 * r);
     }
     struct Piece {
@@ -208,11 +210,7 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
     auto patch_dma = [&](auto rc, const Chunk &c, int buf) {
         constexpr int r = decltype(rc)::value;
         const Piece pc = piece_of(r);
-        int pix = pc.pix;
-        if (c.up) {                                    // nearest-2x source: H and W are powers of two
-            const int ix = pix & (Wd - 1), iy = (pix >> lgW) & (H - 1), bb = pix >> (lgW + lgH);
-            pix = pix < 0 ? -1 : ((((bb << (lgH - 1)) + (iy >> 1)) << (lgW - 1)) + (ix >> 1));
-        }
+        const int pix = pc.pix;
         const unsigned voff = (unsigned)(pix * c.C2 + (pc.lc << 4));
         char *dst = smem + ((r < NROUND - 1 || w < NREMW) ? buf * PATCH_BYTES + r * (NT * 16) + w * 1024 : OFF_DUMP);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(uniform_rsrc(c.src, c.bytes), (lds_ptr_t)dst, 16, voff,
@@ -974,6 +972,7 @@ bool conv_t32_supports(const FusedArgs &a) {
     int nchunks = 0;
     for (int i = 0; i < a.nseg; ++i) {
         if (a.seg[i].C % 32 || a.seg[i].C > 2047) return false;
+        if (a.seg[i].up != a.seg[0].up) return false;      // the piece descriptors carry the source resolution
         if (a.seg[i].taps == 1) seen1 = true;
         else if (seen1) return false;
         else if ((a.seg[i].ss_off >= 0) != (a.seg[0].ss_off >= 0)) return false;   // all 3x3 segments normalised, or none
