@@ -865,14 +865,14 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
     constexpr int RPE = NT / CH;                         // pixel rows handled per pass
     constexpr int NPASS = BM / RPE;
     const int c16 = tid % CH, prw = tid / CH;            // 16-byte chunk (8 channels), pixel row slot
+    // pass i handles tile pixel prw + RPE i, i.e. RPE / 16 image rows further down per pass: one element offset + a stride
+    static_assert(RPE % 16 == 0, "a pass advances by whole tile rows");
+    const size_t e0 = ((size_t)(b * H + y0 + (prw >> 4)) * Wd + x0 + (prw & 15)) * a.Cout + n0 + c16 * 8;
+    const size_t estep = (size_t)(RPE / 16) * Wd * a.Cout;
     v8 rres[NPASS];
     if (a.resid) {
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) {
-            const int pl = prw + RPE * i;
-            const size_t m = (size_t)(b * H + y0 + (pl >> 4)) * Wd + x0 + (pl & 15);
-            rres[i] = *reinterpret_cast<const v8 *>((const T *)a.resid + m * a.Cout + n0 + c16 * 8);
-        }
+        for (int i = 0; i < NPASS; ++i) rres[i] = *reinterpret_cast<const v8 *>((const T *)a.resid + e0 + i * estep);
     }
     float s1[8], s2[8];
 #pragma unroll
@@ -885,8 +885,7 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rres[i][e]);
         }
-        const size_t m = (size_t)(b * H + y0 + (pl >> 4)) * Wd + x0 + (pl & 15);
-        *reinterpret_cast<v8 *>((T *)a.out + m * a.Cout + n0 + c16 * 8) = v;
+        *reinterpret_cast<v8 *>((T *)a.out + e0 + i * estep) = v;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float f = (float)v[e];
