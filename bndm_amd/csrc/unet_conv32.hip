@@ -69,7 +69,8 @@ struct Chunk {
 };
 
 // ABL: profiling switches (results are wrong when non-zero): 1 no MFMA, 2 no weight DMA, 4 no fragment reads,
-// 8 no in-loop patch DMA / normalisation, 16 no in-loop normalisation (DMA kept), 64 record s_memtime marks of
+// 8 no in-loop patch DMA / normalisation, 16 no in-loop normalisation (DMA kept), 128 / 256 prologue without its
+// patch / weight DMAs, 64 record s_memtime marks of
 // block 0 / chunk 1 into dbg[wave][tap][6]
 // NW: waves per workgroup.  4: one wave per SIMD and workgroup, 64 x 128 wave tiles, two workgroups per CU -- for grids
 // of at least two workgroups per CU.  8: 4(M) x 2(N) waves of 64 x 64, two waves per SIMD from ONE workgroup -- for
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
                 self(self, IC<r + 1>{});
             }
         };
-        issue_all(issue_all, IC<0>{});
+        if constexpr (!(ABL & 128)) issue_all(issue_all, IC<0>{});      // (ABL 128 / 256: prologue without its patch / weight DMAs)
         if constexpr (SS) {
             // group 1: patch of chunk 0 (above), tiles 0..2, round 0 of chunk 1; groups 2 and 3 have the shape of the
             // main loop's DMA batches (one patch round, three tiles), so that its counted waits hold from the first barrier
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
             tile(3), tile(4), tile(5);
             round(IC<2>{});
             tile(6), tile(7), tile(8);
-        } else {
+        } else if constexpr (!(ABL & 256)) {
             w_issue(0, 0);
             w_issue(1, 1);
             w_issue(2, 2);
