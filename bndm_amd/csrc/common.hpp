@@ -59,6 +59,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *p, in
 }
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
+// Write-through store (sc0 sc1) for a tensor the NEXT kernel reads.  The L2s of the eight XCDs are not coherent, so the
+// end of a kernel writes every dirty line back to memory before the dependent kernel's loads get through: a kernel that
+// leaves up to 32 MB of freshly written output in the L2s makes its successor wait for that drain behind its first
+// loads.  Written through, the output travels during the kernel and the write-back at its end finds nothing to do.
+template <typename V> __device__ __forceinline__ void store_wt(V *p, const V &v) {
+    static_assert(sizeof(V) == 16 || sizeof(V) == 8 || sizeof(V) == 4, "store_wt: 4, 8 or 16 bytes");
+    // (the wait states behind the 16-byte form: a store of more than 64 bits reads its data registers late, and the hazard
+    // recogniser does not look inside inline assembly -- without them the next VALU write of those registers corrupts it)
+    if constexpr (sizeof(V) == 16)
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else if constexpr (sizeof(V) == 8) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ void wait_vmem_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void iadb_step_kernel(float *__restrict__ x, c
 #pragma unroll
             for (int e = 0; e < 4; ++e) xv[e] = xv[e] + dg * d2[e];
         }
-        reinterpret_cast<f32x4 *>(x)[i] = xv;
+        store_wt(reinterpret_cast<f32x4 *>(x) + i, xv);
     }
 }
 

@@ -827,8 +827,8 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
                 for (int e = 0; e < 4; ++e) {
                     const int co = 8 * g + 4 * kh + e;
                     if (co < a.Cout)
-                        o[((size_t)b * a.Cout + co) * HWs + pix] =
-                            acc[0][j][4 * g + e] + *reinterpret_cast<const float *>(smem + OFF_BIAS + co * 4);
+                        store_wt(o + ((size_t)b * a.Cout + co) * HWs + pix,
+                                 acc[0][j][4 * g + e] + *reinterpret_cast<const float *>(smem + OFF_BIAS + co * 4));
                 }
         }
         return;
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rres[i][e]);
         }
-        *reinterpret_cast<v8 *>((T *)a.out + e0 + i * estep) = v;
+        store_wt(reinterpret_cast<v8 *>((T *)a.out + e0 + i * estep), v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float f = (float)v[e];
@@ -920,7 +920,7 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
             float t = 0.f;
 #pragma unroll
             for (int wv = 0; wv < NW; ++wv) t += red[wv * 2 * NCO + tid];
-            a.stats[((size_t)(b * tps + tin) * a.Cout + n0) * 2 + tid] = t;
+            store_wt(a.stats + ((size_t)(b * tps + tin) * a.Cout + n0) * 2 + tid, t);
         }
     }
     life(5);

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const T *__restrict__ x1,
                 if (silu) f = f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f));
                 o[e] = (T)f;
             }
-            *reinterpret_cast<v8 *>(out + ((size_t)b * HW + p) * C + c0) = o;
+            store_wt(reinterpret_cast<v8 *>(out + ((size_t)b * HW + p) * C + c0), o);
         };
 #pragma unroll
         for (int k = 0; k < GN_SMALL_KEEP; ++k) {

@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float *__restrict__ 
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
     for (int p = prw; p < 128; p += RP) {
         const v8 v = *reinterpret_cast<const v8 *>(smem + p * rowB + ((c16 ^ (p & 15)) << 4));
-        *reinterpret_cast<v8 *>(out + (size_t)(m0 + p) * C0 + c16 * 8) = v;
+        store_wt(reinterpret_cast<v8 *>(out + (size_t)(m0 + p) * C0 + c16 * 8), v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float f = (float)v[e];
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float *__restrict__ 
         for (int i = tid; i < 2 * C0; i += 256) {
             float t = 0.f;
             for (int r = 0; r < RP; ++r) t += red[r * C0 * 2 + i];
-            stats[((size_t)(b0 * nslab + slab) * C0) * 2 + i] = t;
+            store_wt(stats + ((size_t)(b0 * nslab + slab) * C0) * 2 + i, t);
         }
     }
 }

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(TS_NT) void conv_s(const TailArgs a) {
                 v8 ov;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ov[e] = (T)(o[e] * inv);
-                *reinterpret_cast<v8 *>((T *)a.attn_out + (size_t)m * Cout + nt * 32 + hh * 8) = ov;
+                store_wt(reinterpret_cast<v8 *>((T *)a.attn_out + (size_t)m * Cout + nt * 32 + hh * 8), ov);
             }
         }
         return;
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(TS_NT) void conv_s(const TailArgs a) {
                 v8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (T)v[e];
-                *reinterpret_cast<v8 *>((T *)a.raw_out + (size_t)m * Cout + n0 + c8) = o;
+                store_wt(reinterpret_cast<v8 *>((T *)a.raw_out + (size_t)m * Cout + n0 + c8), o);
             }
         } else {
 #pragma unroll
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(TS_NT) void conv_s(const TailArgs a) {
                         if (silu) f = f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f));
                         o[e] = (T)f;
                     }
-                    *reinterpret_cast<v8 *>((T *)outp + (size_t)m * Cout + n0 + c8) = o;
+                    store_wt(reinterpret_cast<v8 *>((T *)outp + (size_t)m * Cout + n0 + c8), o);
                 }
             }
         }
