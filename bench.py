@@ -148,8 +148,15 @@ def self_launch(args, argv):
 # -------------------------------------------------------------------------------------------------
 # workloads
 # -------------------------------------------------------------------------------------------------
-def make_workload(name, B, N, dtype, dev):
-    """-> dict(one_pass, model, res, cin, cout, images_per_pass, metric, workload, extra_stage)"""
+def make_workload(name, B, N, dtype, dev, rank=0, world=1):
+    """-> dict(one_pass, model, res, cin, cout, images_per_pass, metric, workload, extra_stage)
+
+    c4 on more than one GPU is the named configuration "batch = world x 32 sharded": the 128-px blue-noise branch permutes
+    tiles ACROSS the batch (get_noise_recent.py:131-146), so every rank draws the same global batch (one seeded Philox
+    stream per pass, as iadb_bn.py:761 draws one global numpy batch) and computes its own contiguous shard of
+    get_noise_v2's result with ``batch_range`` -- bit-identical to the 1-GPU result on the global batch
+    (tests/test_gpu_noise.py::test_batch_range_sharding_matches_global, at B=256:
+    tests/test_gpu_layouts.py::test_c4_global_batch_256_shards_equal_the_one_gpu_result)."""
     import torch
     from bndm_amd.bluenoise import get_noise_v2
     from bndm_amd.sampler import export_u8, get_model, sample_iadb
@@ -164,13 +171,25 @@ def make_workload(name, B, N, dtype, dev):
         L = torch.from_numpy(blue_noise_factor("blue")).to(dev)
         model = get_model(3, 6, res, dtype=dtype, seed=0).to(dev).eval()
         params = torch.tensor([tau, 0.0, 3.0], device=dev)
-        gamma_T = get_scheduler_gamma(torch.full((B,), float(N), device=dev), "sigmoid", params, N)
-        t_full = torch.full((B,), N, device=dev)
+        sharded = name == "c4" and world > 1
+        BG = B * world if sharded else B                                              # batch the noise branch sees
+        gamma_T = get_scheduler_gamma(torch.full((BG,), float(N), device=dev), "sigmoid", params, N)
+        t_full = torch.full((BG,), N, device=dev)
+        gen = torch.Generator(device=dev)
+        passes = [0]
 
         def one_pass():
-            z = torch.randn(B, 3, res, res, device=dev)                               # on-device Philox
-            x0, _, _ = get_noise_v2(dev, z, L, gamma_T, t_full, noise_type="gaussianBN", train_or_test="test",
-                                    inplace=True, l_is_triangular=True)
+            if sharded:
+                from bndm_amd.parallel import shard_range
+                gen.manual_seed(977 + passes[0])                                       # the SAME global draw on every rank
+                passes[0] += 1
+                z = torch.randn(BG, 3, res, res, device=dev, generator=gen)
+                x0, _, _ = get_noise_v2(dev, z, L, gamma_T, t_full, noise_type="gaussianBN", train_or_test="test",
+                                        inplace=True, l_is_triangular=True, batch_range=shard_range(BG, rank, world))
+            else:
+                z = torch.randn(B, 3, res, res, device=dev)                           # on-device Philox
+                x0, _, _ = get_noise_v2(dev, z, L, gamma_T, t_full, noise_type="gaussianBN", train_or_test="test",
+                                        inplace=True, l_is_triangular=True)
             x = sample_iadb(model, x0, N, "sigmoid", params, 6, "gaussianBN", "train")
             return export_u8(x, "trunc")
         ds = "cat_res64" if name == "c2" else "celeba_res128"
@@ -178,7 +197,9 @@ def make_workload(name, B, N, dtype, dev):
         return dict(one_pass=one_pass, model=model, res=res, cin=3, cout=6, B=B, N=N, L=L,
                     metric=f"images/sec, IADB {res}x{res} UNet, {N} steps, tiled blue noise",
                     workload=f"{ds} IADB, batch={B}/GPU, {N} steps, gaussianBN sigmoid({tau:g},0,3), UNet 3->6, "
-                             f"tiled Gaussian blue noise ({tiles} from 4096^2 L)")
+                             f"tiled Gaussian blue noise ({tiles} from 4096^2 L)" +
+                             (f"; global batch {BG} drawn once per pass, tile permutation over the global batch, "
+                              f"sharded {B}/GPU by batch_range" if sharded else ""))
     if name == "c3":
         from bndm_amd.schedulers import DDIMScheduler
         B, N = B or 64, N or 100
@@ -321,7 +342,7 @@ def main():
     lib = _lib.load()
 
     torch.manual_seed(1234 + rank)
-    wl = make_workload(args.config, args.batch, args.nb_steps, args.dtype, dev)
+    wl = make_workload(args.config, args.batch, args.nb_steps, args.dtype, dev, rank, world)
     B, N, model = wl["B"], wl["N"], wl["model"]
     metric_name, workload_name = wl["metric"], wl["workload"]
 
@@ -452,6 +473,7 @@ def main():
             # c3 / c4 / c5 at their per-GPU batch (1 warm-up + 2 timed passes each), same library, same process
             "other_configs": others,
             "env": env_seen,
+            **({"valid": False, "ablation": env_seen["BNDM_ABLATE"]} if "BNDM_ABLATE" in env_seen else {}),
             # timed on rank 0 of the single-GPU run only (the host cores are shared by the ranks otherwise)
             "cpu_baseline": base,
         }

@@ -804,6 +804,7 @@ struct Builder {
             if (x2 && !rc) out.push_back(TSrc{request_norm(*x2, pname, C1, C, silu), kind, w, C, C1});
             return out;
         }
+        materialize();                      // (this gn_small reads the 16-bit tensors, not a deferred conv's slabs)
         bndm_unet *hh = h;
         Act y = new_act(C, x1.H, x1.W);
         const float *gamma, *beta;
@@ -825,6 +826,7 @@ struct Builder {
     // projection (rows [Wq; Wk; Wv]) + attention of C / 8 heads -> out is the attention output (before to_out)
     Act conv_tail(const std::vector<TSrc> &srcs, int Cout, int H, int W, const float *bias, int temb_off, const Act *resid,
                   const std::string &label, bool qkv = false) {
+        materialize();                      // conv_s reads its sources' 16-bit tensors: a deferred split-K conv is summed first
         bndm_unet *hh = h;
         const int HW = H * W, NB = qkv ? 3 : 1, D = tail_ring_depth(NB), rows = qkv ? 3 * Cout : Cout;
         if (Cout % 32 || (int)srcs.size() > 4) {
@@ -832,6 +834,15 @@ struct Builder {
             rc = BNDM_E_ARG;
             return srcs[0].a;
         }
+        // conv_s addresses its sources and outputs with 32-bit byte offsets
+        for (const TSrc &t : srcs)
+            if ((long long)h->cfg.max_batch * t.a.H * t.a.W * t.a.C * 2 >= (1LL << 31) ||
+                (long long)h->cfg.max_batch * HW * rows * 2 >= (1LL << 31)) {
+                set_error("conv_s: %s exceeds 2 GiB per tensor at max_batch=%d (32-bit offsets); lower max_batch",
+                          label.c_str(), h->cfg.max_batch);
+                rc = BNDM_E_ARG;
+                return srcs[0].a;
+            }
         const int ntn = Cout / 32;
         int TM = 64;
         if (!qkv && HW == 64 && (long long)h->cfg.max_batch * HW / 128 * ntn >= 192) TM = 128;

@@ -87,15 +87,18 @@ def _iadb_loop(model, x0, x_c, nb_step, scheduler_alpha, scheduler_gamma, schedu
         # mean_forward_time: the reference brackets model(...) with time.time() WITHOUT a device synchronise
         # (iadb_bn.py:318-321), i.e. it reports launch time.  Here the whole loop is one asynchronous C call, so the
         # figure is taken from device events around it: (loop time) / steps, forward + Euler update, in seconds.
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        rc = lib.bndm_unet_sample_iadb(h, _ptr(x), _ptr(xc), B, Cc, nb_step, t_in.ctypes.data_as(C.c_void_p),
-                                       da.ctypes.data_as(C.c_void_p), dgz.ctypes.data_as(C.c_void_p),
-                                       mask.ctypes.data_as(C.c_void_p), _ptr(snaps), _lib.current_stream_ptr())
-        _lib.check(rc, "bndm_unet_sample_iadb")
-        e1.record()
+        # The events go onto x's device and onto the very stream handed to the library.
+        with torch.cuda.device(x.device):
+            st = torch.cuda.current_stream(x.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            rc = lib.bndm_unet_sample_iadb(h, _ptr(x), _ptr(xc), B, Cc, nb_step, t_in.ctypes.data_as(C.c_void_p),
+                                           da.ctypes.data_as(C.c_void_p), dgz.ctypes.data_as(C.c_void_p),
+                                           mask.ctypes.data_as(C.c_void_p), _ptr(snaps), C.c_void_p(st.cuda_stream))
+            _lib.check(rc, "bndm_unet_sample_iadb")
+            e1.record(st)
         if train_or_test == "test":                     # only the 'test' form returns the figure (utils.py:237-240)
-            e1.synchronize()
+            e1.synchronize()                            # (the reference's 'test' callers move x to the host right after)
             times = [e0.elapsed_time(e1) * 1e-3 / max(nb_step, 1)] * 2
     else:
         k = 0
@@ -124,7 +127,10 @@ def _iadb_loop(model, x0, x_c, nb_step, scheduler_alpha, scheduler_gamma, schedu
 def sample_iadb(model, x0, nb_step, scheduler_gamma, scheduler_params, out_channel, noise_type, train_or_test,
                 scheduler_alpha='linear', log_freq=1, alpha_param=0.02):
     """utils.sample_iadb (utils.py:179).  Returns (x, x_all, mean_forward_time) in 'test' mode and x
-    otherwise.  ``log_freq`` (extra, default = utils.py's 1) selects iadb_bn.py's cadence of 25;
+    otherwise.  ``mean_forward_time`` is NOT the reference's un-synchronised host time around model(...)
+    (iadb_bn.py:318-321, i.e. launch time): with the in-engine loop it is (device time of the whole loop) / steps --
+    forward + Euler update + snapshots, in seconds, from events on the stream the library ran on; reading it
+    synchronises that stream.  ``log_freq`` (extra, default = utils.py's 1) selects iadb_bn.py's cadence of 25;
     ``alpha_param`` is the sigmoid start / cosine tau of a non-linear ``scheduler_alpha`` -- iadb_bn.py passes
     ``opt.scheduler_param`` there (iadb_bn.py:115,131)."""
     x, x_all, ft = _iadb_loop(model, x0, None, nb_step, scheduler_alpha, scheduler_gamma, scheduler_params,
