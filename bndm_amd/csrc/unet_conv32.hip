@@ -23,6 +23,7 @@
 #include "unet_types.hpp"
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 namespace bndm {
@@ -57,6 +58,7 @@ typedef uint32_t u32x4t __attribute__((ext_vector_type(4)));
 
 constexpr int T32_MAX_CHUNKS = 32;
 constexpr int T32_SS_BYTES = 4096;           // scale/shift table [2][ssC] fp32, ssC <= 512
+constexpr float T32_LOG2E = 1.4426950408889634f;
 
 // wave-uniform description of one 32-channel chunk of a segment
 struct Chunk {
@@ -225,33 +227,48 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
         constexpr int r = decltype(rc)::value;
         x = *reinterpret_cast<const u32x4 *>(smem + buf * PATCH_BYTES + r * (NT * 16) + tid * 16);
     };
+    // (padding / tail pieces are not written back: they stay the zeros the DMA left.  The select is on the address -- one
+    // v_cndmask per piece instead of one per dword -- and the losers land in the dead slot)
     auto xf_end = [&](auto rc, int buf, const u32x4 &x) {
         constexpr int r = decltype(rc)::value;
-        *reinterpret_cast<u32x4 *>(smem + buf * PATCH_BYTES + r * (NT * 16) + tid * 16) = x;
+        const int real = buf * PATCH_BYTES + r * (NT * 16) + tid * 16, dead = OFF_DUMP + l * 16;
+        *reinterpret_cast<u32x4 *>(smem + (piece_of(r).valid ? real : dead)) = x;
     };
-    auto norm2 = [&](unsigned xq, float s0, float s1, float h0, float h1, bool valid) {
+    // Two elements (one dword) of GroupNorm scale/shift + SiLU.  The table holds log2(e) * (scale, shift), so
+    //     y' = s' x + h' = log2(e) y,   o' = y' / (1 + 2^-y') = log2(e) silu(y),
+    // and the weights of a normalised segment are packed multiplied by ln 2 (conv_fused): the multiplication by -log2(e)
+    // in front of the exponential is gone (the negation is a source modifier).  This file is compiled with
+    // -fno-slp-vectorize: the SLP vectoriser pairs the two elements into v_pk_fma_f32 / v_pk_mul_f32 (half-rate beside
+    // MFMAs, + wait states) and thereby blocks v_fma_mix_f32, which reads the f16 halves directly -- 7 plain + 4
+    // transcendental issues per dword instead of 13 + 4.
+    auto norm2 = [&](unsigned xq, float s0, float s1, float h0, float h1) -> unsigned {
         const v2 in = __builtin_bit_cast(v2, xq);
         v2 o;
         const float f0 = fmaf((float)in[0], s0, h0), f1 = fmaf((float)in[1], s1, h1);
-        o[0] = (T)(f0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f0)));
-        o[1] = (T)(f1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f1)));
-        return valid ? __builtin_bit_cast(unsigned, o) : xq;
+        o[0] = (T)(f0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-f0)));
+        o[1] = (T)(f1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-f1)));
+        return __builtin_bit_cast(unsigned, o);
     };
     // half h (0 / 1) of round r of chunk c: dwords 2h, 2h+1 of the piece = channels 4h .. 4h+3 of its group
     auto xf_half = [&](auto rc, auto hc, const Chunk &c, u32x4 &x) {
         constexpr int r = decltype(rc)::value, h = decltype(hc)::value;
         const Piece pc = piece_of(r);
-        const bool valid = pc.valid;
         const float *sc = ssL + c.ssbase + pc.lc * 8 + 4 * h;
         const f32x4 s4 = *reinterpret_cast<const f32x4 *>(sc), h4 = *reinterpret_cast<const f32x4 *>(sc + a.ssC);
-        x[2 * h] = norm2(x[2 * h], s4[0], s4[1], h4[0], h4[1], valid);
-        x[2 * h + 1] = norm2(x[2 * h + 1], s4[2], s4[3], h4[2], h4[3], valid);
+        x[2 * h] = norm2(x[2 * h], s4[0], s4[1], h4[0], h4[1]);
+        x[2 * h + 1] = norm2(x[2 * h + 1], s4[2], s4[3], h4[2], h4[3]);
     };
     auto xf_owner = [&](int r) { return r < NROUND - 1 || w < NREMW; };    // wave-uniform
 
     // ---- weight tiles: [128 rows][64 B] per K-step, packed per (n-tile, step) as one linear 8 KiB block ----------
     const __amdgpu_buffer_rsrc_t wrs =
         uniform_rsrc((const char *)a.Wgt + (size_t)nt * nsteps_w * W_BYTES, nsteps_w * W_BYTES);
+    auto w_issue1 = [&](int slot, int step, int i) {   // piece i (< NWP) of a tile
+        char *base = smem + (w < NWW ? OFF_W + slot * W_BYTES + w * 1024 : OFF_DUMP);
+        const int so = __builtin_amdgcn_readfirstlane(step * W_BYTES);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(base + i * (NT * 16)), 16,
+                                                 w < NWW ? (unsigned)(tid * 16 + i * (NT * 16)) : 0x80000000u, so, 0, 0);
+    };
     auto w_issue = [&](int slot, int step) {
         char *base = smem + (w < NWW ? OFF_W + slot * W_BYTES + w * 1024 : OFF_DUMP);   // (narrow tiles: the other waves' DMA
         const int so = __builtin_amdgcn_readfirstlane(step * W_BYTES);                  //  reads past the tile = zeros, dumped)
@@ -321,6 +338,63 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
                 for (int j = 0; j < TM; ++j) acc[i][j] = TT<T>::mfma(fa[i], fb[ks][j], acc[i][j]);
             }
             read_a(tnext, knext, i);
+        }
+    };
+
+    // One phase in PINNED order (scheduling fences instead of sched_group_barrier patterns, whose greedy solver bunches
+    // the normalisation arithmetic at the head of a phase as soon as its instruction mix changes):
+    //     [patch fragment reads]  { [MFMAs of weight tile i] | [its refill read, extra(i)] } x TN
+    // extra(i): the i-th LDS-DMA of the phase and stage i of the normalisation, supplied by the caller.
+    auto phase_pinned = [&](auto kcur, auto tnext, auto knext, auto &&extra) {
+        constexpr int ks = decltype(kcur)::value;
+        read_b(tnext, knext);
+        auto grp = [&](auto self, auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i < TN) {
+                if (ABL & 1) {
+                    asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(fb[ks][j]));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) acc[i][j] = TT<T>::mfma(fa[i], fb[ks][j], acc[i][j]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                read_a(tnext, knext, i);
+                extra(ic);
+                __builtin_amdgcn_sched_barrier(0);
+                self(self, IC<i + 1>{});
+            }
+        };
+        grp(grp, IC<0>{});
+    };
+    // normalisation of two dwords (four elements) in three stages that ride behind successive MFMA groups: every stage
+    // is four independent chains, and a transcendental's consumer sits a whole MFMA group behind it
+    constexpr int STG_B = TN >= 2 ? 1 : 0, STG_C = TN >= 3 ? 2 : TN - 1;
+    auto norm_stage = [&](auto ic, auto pc, u32x4 &xv, const f32x4 &sv, const f32x4 &hv, float (&ny)[4], float (&ne)[4]) {
+        constexpr int i = decltype(ic)::value, p = decltype(pc)::value;
+        if constexpr (i == 0) {
+            const unsigned x0 = xv[2 * p], x1 = xv[2 * p + 1];
+            const v2 i0 = __builtin_bit_cast(v2, x0), i1 = __builtin_bit_cast(v2, x1);
+            ny[0] = fmaf((float)i0[0], sv[0], hv[0]);
+            ny[1] = fmaf((float)i0[1], sv[1], hv[1]);
+            ny[2] = fmaf((float)i1[0], sv[2], hv[2]);
+            ny[3] = fmaf((float)i1[1], sv[3], hv[3]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ne[k] = __builtin_amdgcn_exp2f(-ny[k]);
+        }
+        if constexpr (i == STG_B) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ne[k] = __builtin_amdgcn_rcpf(1.0f + ne[k]);
+        }
+        if constexpr (i == STG_C) {
+            v2 o0, o1;
+            o0[0] = (T)(ny[0] * ne[0]);
+            o0[1] = (T)(ny[1] * ne[1]);
+            o1[0] = (T)(ny[2] * ne[2]);
+            o1[1] = (T)(ny[3] * ne[3]);
+            xv[2 * p] = __builtin_bit_cast(unsigned, o0);
+            xv[2 * p + 1] = __builtin_bit_cast(unsigned, o1);
         }
     };
 
@@ -436,12 +510,17 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
                 var = var > 0 ? var : 0;
                 const float rstd = (float)(1.0 / sqrt(var + (double)a.gn_eps));
                 const float sc = rstd * gam[k2];
-                ssW[c] = sc;
-                ssW[C + c] = bet[k2] - (float)mean * sc;
+                ssW[c] = T32_LOG2E * sc;                                   // (norm2: the table carries log2(e))
+                ssW[C + c] = T32_LOG2E * (bet[k2] - (float)mean * sc);
             }
         }
         life(9);
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(SS ? 8 : 4 * NWP) : "memory");   // table + own patch pieces landed
+        if (!a.gn_p1 && w < 4) {                             // a table from memory (gn_finalize2): own piece times log2(e)
+            f32x4 *tp = reinterpret_cast<f32x4 *>(smem + OFF_SS + tid * 16);
+            *tp = *tp * T32_LOG2E;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();                         // ... in every wave (the table is shared)
         asm volatile("" ::: "memory");
         life(10);
@@ -514,14 +593,13 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
                 ha = *reinterpret_cast<const f32x4 *>(sc4 + a.ssC);
             }
         };
-        auto xf_math = [&](auto sc, auto pc) {
-            constexpr int s = decltype(sc)::value, p = decltype(pc)::value;
+        float ny[4] = {0.f, 0.f, 0.f, 0.f}, ne[4] = {0.f, 0.f, 0.f, 0.f};
+        auto xf_math = [&](auto sc, auto pc, auto ic) {          // stage ic of the window position (s, p)
+            constexpr int s = decltype(sc)::value, p = decltype(pc)::value, i = decltype(ic)::value;
             constexpr int r = s >= 3 && s <= 7 && s - 3 < NFULL ? s - 3 : -1;
             if constexpr (DOX && r >= 0) {
-                const bool valid = piece_of(r).valid;
-                xa[2 * p] = norm2(xa[2 * p], sa[0], sa[1], ha[0], ha[1], valid);
-                xa[2 * p + 1] = norm2(xa[2 * p + 1], sa[2], sa[3], ha[2], ha[3], valid);
-                if constexpr (p == 1) xf_end(IC<r>{}, pbuf ^ 1, xa);
+                norm_stage(ic, pc, xa, sa, ha, ny, ne);
+                if constexpr (p == 1 && i == STG_C) xf_end(IC<r>{}, pbuf ^ 1, xa);
             }
         };
         // the partial last round (pieces of waves < NREMW only): in one go at the end of the last window (the
@@ -539,32 +617,21 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
                 }
             }
         };
-        // MFMAs of a phase with everything else of the phase issued in their shadow: per MFMA one fragment read (the
-        // next phase's operands), one LDS-DMA while there are any, and a share of the normalisation arithmetic.  Without
-        // the interleave the compiler issues the six reads (and the DMAs) first and the MFMA pipe sits idle meanwhile.
-        auto phase = [&](auto kcur, auto tnext, auto knext, auto sc, auto pc, auto nvm) {
-            constexpr int s = decltype(sc)::value, NVMEM = decltype(nvm)::value;
-            constexpr int r = s >= 3 && s <= 7 && s - 3 < NFULL ? s - 3 : -1;
-            // the phase is its own scheduling region: the group pattern below must only see this phase's instructions
+        // MFMAs of a phase with everything else of the phase issued in their shadow, in pinned order (phase_pinned): per
+        // MFMA group one fragment read (the next phase's operands), one LDS-DMA while there are any (dma(i)), and one stage
+        // of the normalisation arithmetic.
+        auto phase = [&](auto kcur, auto tnext, auto knext, auto sc, auto pc, auto &&dma) {
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(ABL & 512)) __builtin_amdgcn_s_setprio(1);      // two independent workgroups per SIMD: the MFMA
                                                                            // phase of one outranks the other's DMA issue / VALU
-            mma_refill(kcur, tnext, knext);
-            xf_math(sc, pc);
-            if constexpr (!(ABL & 1) && !(ABL & 4) && !(ABL & 32)) {
-                constexpr int NV = DOX && r >= 0 ? 11 : 2;
-                __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);                             // patch fragments first
-#pragma unroll
-                for (int i = 0; i < TN; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);                         // MFMAs of weight tile i
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          // its refill
-                    if (i < NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // 1 LDS-DMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                         // VALU in the shadow
-                }
-            }
+            phase_pinned(kcur, tnext, knext, [&](auto ic) {
+                dma(ic);
+                xf_math(sc, pc, ic);
+            });
             if constexpr (!(ABL & 512)) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         };
+        auto no_dma = [](auto) {};
         auto mark = [&](int t, int k) {
             if constexpr ((ABL & 64) != 0) {
                 if (blockIdx.x == 0 && c == 1) {
@@ -578,7 +645,7 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
             mark(t, 0);
             // first phase: MFMAs of (tap t, k 0..15); reads of (tap t, k 16..31); then the LDS reads of the normalisation
             // slice that rides under the second phase, so that they return during the wait / barrier
-            phase(IC<0>{}, tc, IC<1>{}, IC<t - 1>{}, IC<1>{}, IC<0>{});
+            phase(IC<0>{}, tc, IC<1>{}, IC<t - 1>{}, IC<1>{}, no_dma);
             xf_tail(IC<t - 1>{}, IC<1>{});
             xf_pre(tc, IC<0>{});
             // advance the weight ring (and, at the last tap, the chunk) before the reads of the next step
@@ -606,21 +673,31 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             mark(t, 3);
-            // second phase: DMA group G_t; MFMAs of (tap t, k 16..31); reads of (tap t+1, k 0..15)
-            if (!(ABL & 2)) {
-                // tile of step t+4 (wstep was advanced: it is the index of step t+1)
+            // second phase: DMA group G_t, one DMA behind each MFMA group; MFMAs of (tap t, k 16..31); reads of (tap t+1, k 0..15)
+            {
+                // tile of step t+4 (wstep was advanced: it is the index of step t+1) -> the slot of tile t
                 const int ws = wstep + 3 < nstep9 ? wstep + 3 : nstep9 - 1;
-                w_issue((slot + 3) & (WSTAGES - 1), ws);         // slot was advanced: the slot of tile t
+                const int wslot = (slot + 3) & (WSTAGES - 1);
+                constexpr int R0 = rounds_per_tap(NROUND) * t, NR = rounds_at_tap(NROUND, t), ND = NWP + NR;
+                // DMA k of the group (weight pieces, then patch rounds) goes behind MFMA group k, the overflow behind the last
+                phase(IC<1>{}, IC<(t + 1) % 9>{}, IC<0>{}, tc, IC<0>{}, [&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    auto one = [&](auto self, auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        if constexpr (k < ND) {
+                            if constexpr (k == i || (i == TN - 1 && k >= TN)) {
+                                if constexpr (k < NWP) {
+                                    if (!(ABL & 2)) w_issue1(wslot, ws, k);
+                                } else {
+                                    if (!(ABL & 8)) patch_dma(IC<(k < ND ? R0 + k - NWP : 0)>{}, nxt, pbuf ^ 1);
+                                }
+                            }
+                            self(self, IC<k + 1>{});
+                        }
+                    };
+                    one(one, IC<0>{});
+                });
             }
-            if constexpr (rounds_at_tap(NROUND, t) > 0) {
-                if (!(ABL & 8)) {
-                    constexpr int R0 = rounds_per_tap(NROUND) * t, NR = rounds_at_tap(NROUND, t);
-                    static_assert(NR <= 2, "at most two patch rounds per tap");
-                    patch_dma(IC<R0>{}, nxt, pbuf ^ 1);
-                    if constexpr (NR > 1) patch_dma(IC<(NR > 1 ? R0 + 1 : 0)>{}, nxt, pbuf ^ 1);
-                }
-            }
-            phase(IC<1>{}, IC<(t + 1) % 9>{}, IC<0>{}, tc, IC<0>{}, IC<NWP + rounds_at_tap(NROUND, t)>{});
             xf_pre(tc, IC<1>{});                                 // for the first phase of the next step
             mark(t, 4);
         };
@@ -669,39 +746,30 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
                 }
             }
         };
-        auto xs_math = [&](auto sc, auto pc) {
-            constexpr int s = decltype(sc)::value, p = decltype(pc)::value;
+        float ny[4] = {0.f, 0.f, 0.f, 0.f}, ne[4] = {0.f, 0.f, 0.f, 0.f};
+        auto xs_math = [&](auto sc, auto pc, auto ic) {
+            constexpr int s = decltype(sc)::value, p = decltype(pc)::value, i = decltype(ic)::value;
             constexpr int r = s >= 0 && s % 3 == 0 && s / 3 < NROUND ? s / 3 : -1;
             if constexpr (DOX && r >= 0) {
                 if (xf_owner(r)) {
-                    const bool valid = piece_of(r).valid;
-                    xa[2 * p] = norm2(xa[2 * p], sa[0], sa[1], ha[0], ha[1], valid);
-                    xa[2 * p + 1] = norm2(xa[2 * p + 1], sa[2], sa[3], ha[2], ha[3], valid);
-                    if constexpr (p == 1) xf_end(IC<r>{}, b1, xa);
+                    norm_stage(ic, pc, xa, sa, ha, ny, ne);
+                    if constexpr (p == 1 && i == STG_C) xf_end(IC<r>{}, b1, xa);
                 }
             }
         };
-        auto phase = [&](auto kcur, auto tnext, auto knext, auto sc, auto pc, auto nvm) {
-            constexpr int s = decltype(sc)::value, NVMEM = decltype(nvm)::value;
-            constexpr int r = s >= 0 && s % 3 == 0 && s / 3 < NROUND ? s / 3 : -1;
+        auto phase = [&](auto kcur, auto tnext, auto knext, auto sc, auto pc, auto &&dma) {
             __builtin_amdgcn_sched_barrier(0);
-            mma_refill(kcur, tnext, knext);
-            xs_math(sc, pc);
-            constexpr int NV = DOX && r >= 0 ? 11 : 2;
-            __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
-#pragma unroll
-            for (int i = 0; i < TN; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (2 * i < NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);               // (NVMEM is 0 or 4)
-                __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
-            }
+            phase_pinned(kcur, tnext, knext, [&](auto ic) {
+                dma(ic);
+                xs_math(sc, pc, ic);
+            });
             __builtin_amdgcn_sched_barrier(0);
         };
+        auto no_dma = [](auto) {};
         auto step = [&](auto tc) {
             constexpr int t = decltype(tc)::value;
             mark(t, 0);
-            phase(IC<0>{}, tc, IC<1>{}, IC<t - 1>{}, IC<1>{}, IC<0>{});
+            phase(IC<0>{}, tc, IC<1>{}, IC<t - 1>{}, IC<1>{}, no_dma);
             xs_pre(tc, IC<0>{});
             mark(t, 1);
             if constexpr (t % 3 == 2) {
@@ -718,13 +786,11 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 mark(t, 3);
-                if constexpr (j < NROUND && !(ABL & 8)) patch_dma(IC<(j < NROUND ? j : 0)>{}, nx2, b2);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(smem + OFF_DUMP), 16, 0x80000000u, 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const int ws = 9 * c + 3 * j + 9 + i;
-                    if (!(ABL & 2)) w_issue(3 * j + i, ws < nstep9 ? ws : nstep9 - 1);
-                }
+                // the DMA batch: patch round j (or its stand-in) and tile 0 behind the first MFMA group, tiles 1 and 2 behind
+                // the second.  (b1 / b2 / nxt / nx2 advance at t == 8 BEFORE the phase: the batch then belongs to the roles of
+                // the next chunk -- so the round's chunk and buffer are taken now.)
+                const Chunk dch = nx2;
+                const int dbuf = b2;
                 if constexpr (t == 8) {
                     const int b0 = b1;
                     b1 = b2;
@@ -732,9 +798,24 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
                     nxt = nx2;
                     nx2 = load_chunk(c + 3 < nchunk9 ? c + 3 : nchunk9 - 1);
                 }
-                phase(IC<1>{}, IC<(t + 1) % 9>{}, IC<0>{}, tc, IC<0>{}, IC<1 + 3 * NWP>{});
+                static_assert(!SS || (TN == 2 && NWP == 1), "super-step DMA batch: two DMAs behind each of two MFMA groups");
+                phase(IC<1>{}, IC<(t + 1) % 9>{}, IC<0>{}, tc, IC<0>{}, [&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    auto tile = [&](int k) {
+                        const int ws = 9 * c + 3 * j + 9 + k;
+                        if (!(ABL & 2)) w_issue(3 * j + k, ws < nstep9 ? ws : nstep9 - 1);
+                    };
+                    if constexpr (i == 0) {
+                        if constexpr (j < NROUND && !(ABL & 8)) patch_dma(IC<(j < NROUND ? j : 0)>{}, dch, dbuf);
+                        else __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(smem + OFF_DUMP), 16, 0x80000000u, 0, 0, 0);
+                        tile(0);
+                    } else {
+                        tile(1);
+                        tile(2);
+                    }
+                });
             } else {
-                phase(IC<1>{}, IC<(t + 1) % 9>{}, IC<0>{}, tc, IC<0>{}, IC<0>{});
+                phase(IC<1>{}, IC<(t + 1) % 9>{}, IC<0>{}, tc, IC<0>{}, no_dma);
             }
             xs_pre(tc, IC<1>{});
             mark(t, 4);

@@ -585,9 +585,12 @@ struct Builder {
                 rc = BNDM_E_ARG;
                 return;
             }
+            // conv_t32 normalises to log2(e) * silu(.) (one multiplication less per element, unet_conv32.hip: norm2): the
+            // weights of a normalised segment carry the ln 2
             const std::vector<float> wp = pack_weights_t32(a.seg, a.nseg, out.C, [&](int si, int co, int c, int t) {
                 const WSeg &w = ws[si];
-                return (*w.w)[((size_t)co * w.cin_total + w.c_begin + c) * w.taps + t];
+                const float v = (*w.w)[((size_t)co * w.cin_total + w.c_begin + c) * w.taps + t];
+                return a.seg[si].ss_off >= 0 ? 0.6931471805599453f * v : v;
             }, head ? 32 : 128);
             if ((rc = upload_16(h, wp, &Wp))) return;
         }
