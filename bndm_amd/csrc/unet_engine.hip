@@ -365,7 +365,7 @@ int pack_conv_weight(bndm_unet *h, const std::vector<WSeg> &segs, int Cout, int 
 // graph construction
 // ------------------------------------------------------------------------------------------------
 struct StatRef {
-    int pslot = -1;   // buffer slot of partial sums [B][nslab][C][2]
+    int pslot = -1;   // buffer slot of partial sums [B][nslab][C / 2][2] (per channel pair)
     int nslab = 0;
 };
 
@@ -411,7 +411,7 @@ struct Builder {
         if (it != stats_of.end()) return it->second;
         bndm_unet *hh = h;
         const int HW = x.H * x.W, nslab = gn_num_slabs(HW), C = x.C;
-        StatRef sr{h->new_slot((size_t)h->cfg.max_batch * nslab * C * 2 * 4), nslab};
+        StatRef sr{h->new_slot((size_t)h->cfg.max_batch * nslab * (C / 2) * 2 * 4), nslab};
         const int sx = x.slot, sp = sr.pslot;
         cur_name = S("gnst %-44s C=%-4d %dx%d", "", C, x.H, x.W);
         push(OPC_OTHER, 0, [=](RunCtx &r) {
@@ -421,7 +421,7 @@ struct Builder {
         return sr;
     }
     StatRef new_stats(const Act &x, int nslab) {
-        StatRef sr{h->new_slot((size_t)h->cfg.max_batch * nslab * x.C * 2 * 4), nslab};
+        StatRef sr{h->new_slot((size_t)h->cfg.max_batch * nslab * (x.C / 2) * 2 * 4), nslab};
         stats_of[x.slot] = sr;
         return sr;
     }
@@ -441,6 +441,11 @@ struct Builder {
         bndm_unet *hh = h;
         GnSpec g;
         const int C1 = x1.C, C2 = x2 ? x2->C : 0, C = C1 + C2, HW = x1.H * x1.W;
+        if (C % (2 * GROUPS) || C1 % 2 || C2 % 2) {       // the partial sums are per channel pair
+            set_error("GroupNorm %s: %d+%d channels -- groups must have an even number of channels", pname.c_str(), C1, C2);
+            rc = BNDM_E_ARG;
+            return g;
+        }
         const StatRef a1 = ensure_stats(x1);
         const StatRef a2 = x2 ? ensure_stats(*x2) : StatRef{};
         const float *gamma, *beta;

@@ -7,7 +7,8 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 if [ ! -f $R/tools/libbndm_ablate.so ] || [ "$1" = "--build" ]; then
   mkdir -p /tmp/bndm_ablate && cd $R/bndm_amd/csrc &&
   for f in core bluenoise steps unet_kernels unet_gn unet_conv32 unet_tail unet_f32 unet_engine; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DBNDM_ABLATION -I../../include -c $f.hip -o /tmp/bndm_ablate/$f.o || exit 1
+    x=""; [ $f = unet_conv32 ] && x="-fno-slp-vectorize"      # (as the Makefile builds it)
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $x -DBNDM_ABLATION -I../../include -c $f.hip -o /tmp/bndm_ablate/$f.o || exit 1
   done && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/libbndm_ablate.so /tmp/bndm_ablate/*.o
   [ "$1" = "--build" ] && exit 0
 fi
