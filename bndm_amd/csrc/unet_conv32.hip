@@ -504,19 +504,27 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
             asm volatile("" ::: "memory");
             life(8);
             const int Cg = gC >> 5, Pg = Cg >> 1;                 // channels / pairs per group (Cg is even: conv_t32_supports)
-            if (tid < 32) {
+            if (tid < 256) {
+                // eight lanes per group: the G * Pg partial sums of a group dealt round-robin, then a fixed butterfly (one
+                // thread per group walking them serially was ~2 K clocks of dependent LDS latency with eight waves waiting)
+                const int g = tid >> 3, jl = tid & 7, nitem = G * Pg;
                 double s = 0, q2 = 0;
-                for (int g2 = 0; g2 < G; ++g2)
-                    for (int k = 0; k < Pg; ++k) {
-                        const float2 v = part[g2 * (gC >> 1) + tid * Pg + k];
-                        s += v.x;
-                        q2 += v.y;
-                    }
+                for (int e = jl; e < nitem; e += 8) {
+                    const int g2 = e / Pg, k = e - g2 * Pg;
+                    const float2 v = part[g2 * (gC >> 1) + g * Pg + k];
+                    s += v.x;
+                    q2 += v.y;
+                }
+#pragma unroll
+                for (int m = 1; m < 8; m <<= 1) {
+                    s += __shfl_xor(s, m);
+                    q2 += __shfl_xor(q2, m);
+                }
                 const double n = (double)Cg * a.gn_HW;
                 const double mean = s / n;
                 double var = q2 / n - mean * mean;
                 var = var > 0 ? var : 0;
-                gst[tid] = float2{(float)mean, (float)(1.0 / sqrt(var + (double)a.gn_eps))};
+                if (jl == 0) gst[g] = float2{(float)mean, (float)(1.0 / sqrt(var + (double)a.gn_eps))};
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
