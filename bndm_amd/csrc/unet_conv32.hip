@@ -84,7 +84,7 @@ struct Chunk {
 // tiles (= one chunk: tap t lives in slot t) filled two super-steps ahead, three patch buffers (the chunk after next is
 // DMA'd while the next one is normalised).  Same MFMA order as the per-tap schedule, i.e. bit-identical results.
 template <typename T, int TH, int ABL, int NW, int NCO, int SS = 0>
-__global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs a, const int tiles_x, const int tps, const int ntn,
+__global__ __launch_bounds__(NW * 64, (SS || TH == 32) ? 1 : 2) void conv_t32(const FusedArgs a, const int tiles_x, const int tps, const int ntn,
                                                    const int nsteps_w, unsigned *__restrict__ dbg) {
     using v8 = typename TT<T>::v8;
     using v4 = typename TT<T>::v4;
@@ -600,38 +600,62 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
     // step s+1).  A partial last round (only the first NREMW waves own pieces of it) gets a window of its own -- done in
     // one go at the end of the last window it kept the other waves waiting at B_8 for ~600 clocks per chunk.
     constexpr bool PARTIAL = NREMW < NW;
-    constexpr int W0 = PARTIAL ? 8 - NROUND : 3;
-    static_assert(W0 >= 2 && W0 + NROUND <= 8, "normalisation schedule: one round per window of steps W0..7");
+    constexpr int RPW = NROUND > 6 ? 2 : 1;                // rounds per window (the 512-pixel tile has ten rounds)
+    constexpr int NWIN = (NROUND + RPW - 1) / RPW;
+    constexpr int W0 = (PARTIAL || RPW > 1) ? 8 - NWIN : 3;
+    static_assert(W0 >= 2 && W0 + NWIN <= 8, "normalisation schedule: RPW rounds per window of steps W0..7");
     auto chunk_body = [&](auto doxc, const int c) __attribute__((always_inline)) {
         constexpr bool DOX = decltype(doxc)::value != 0 && !(ABL & 8) && !(ABL & 16);
-        u32x4 xa = {0u, 0u, 0u, 0u};                           // round in flight
-        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, ha = {0.f, 0.f, 0.f, 0.f};
+        u32x4 xa[RPW];                                         // rounds in flight
+        f32x4 sa[RPW], ha[RPW];
+        float ny[RPW][4], ne[RPW][4];
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            xa[q] = u32x4{0u, 0u, 0u, 0u};
+            sa[q] = ha[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ny[q][k] = ne[q][k] = 0.f;
+        }
         // window of step s (W0..7): position 0 = second phase of step s, position 1 = first phase of step s+1; it
-        // normalises round s - W0, four channels per position
+        // normalises rounds RPW (s - W0) .. + RPW - 1, four channels of each per position
         // xf_pre: LDS reads of a position, issued at the end of the phase before it (they return during the barrier wait)
         auto xf_pre = [&](auto sc, auto pc) {
             constexpr int s = decltype(sc)::value, p = decltype(pc)::value;
-            constexpr int r = s >= W0 && s <= 7 && s - W0 < NROUND ? s - W0 : -1;
-            if constexpr (DOX && r >= 0) {
-                // own piece landed?  (G_s is issued later in this phase: count up to G_(s-1))
-                if constexpr (p == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dmas_after_round(NROUND, NWP, r, s - 1)) : "memory");
-                if (xf_owner(r)) {                               // (wave-uniform; constant for all but a partial last round)
-                    if constexpr (p == 0) xf_begin(IC<r>{}, pbuf ^ 1, xa);
-                    const float *sc4 = ssL + nxt.ssbase + piece_of(r).lc * 8 + 4 * p;
-                    sa = *reinterpret_cast<const f32x4 *>(sc4);
-                    ha = *reinterpret_cast<const f32x4 *>(sc4 + a.ssC);
-                }
+            constexpr int r0 = s >= W0 && s <= 7 && RPW * (s - W0) < NROUND ? RPW * (s - W0) : -1;
+            if constexpr (DOX && r0 >= 0) {
+                constexpr int rl = r0 + RPW - 1 < NROUND ? r0 + RPW - 1 : NROUND - 1;     // last round of the window
+                // own pieces landed?  (G_s is issued later in this phase: count up to G_(s-1); rounds retire in order)
+                if constexpr (p == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dmas_after_round(NROUND, NWP, rl, s - 1)) : "memory");
+                auto one = [&](auto qc) {
+                    constexpr int q = decltype(qc)::value, r = r0 + q;
+                    if constexpr (r < NROUND) {
+                        if (xf_owner(r)) {                       // (wave-uniform; constant for all but a partial last round)
+                            if constexpr (p == 0) xf_begin(IC<r>{}, pbuf ^ 1, xa[q]);
+                            const float *sc4 = ssL + nxt.ssbase + piece_of(r).lc * 8 + 4 * p;
+                            sa[q] = *reinterpret_cast<const f32x4 *>(sc4);
+                            ha[q] = *reinterpret_cast<const f32x4 *>(sc4 + a.ssC);
+                        }
+                    }
+                };
+                one(IC<0>{});
+                if constexpr (RPW > 1) one(IC<RPW - 1>{});
             }
         };
-        float ny[4] = {0.f, 0.f, 0.f, 0.f}, ne[4] = {0.f, 0.f, 0.f, 0.f};
         auto xf_math = [&](auto sc, auto pc, auto ic) {          // stage ic of the window position (s, p)
             constexpr int s = decltype(sc)::value, p = decltype(pc)::value, i = decltype(ic)::value;
-            constexpr int r = s >= W0 && s <= 7 && s - W0 < NROUND ? s - W0 : -1;
-            if constexpr (DOX && r >= 0) {
-                if (xf_owner(r)) {
-                    norm_stage(ic, pc, xa, sa, ha, ny, ne);
-                    if constexpr (p == 1 && i == STG_C) xf_end(IC<r>{}, pbuf ^ 1, xa);
-                }
+            constexpr int r0 = s >= W0 && s <= 7 && RPW * (s - W0) < NROUND ? RPW * (s - W0) : -1;
+            if constexpr (DOX && r0 >= 0) {
+                auto one = [&](auto qc) {
+                    constexpr int q = decltype(qc)::value, r = r0 + q;
+                    if constexpr (r < NROUND) {
+                        if (xf_owner(r)) {
+                            norm_stage(ic, pc, xa[q], sa[q], ha[q], ny[q], ne[q]);
+                            if constexpr (p == 1 && i == STG_C) xf_end(IC<r>{}, pbuf ^ 1, xa[q]);
+                        }
+                    }
+                };
+                one(IC<0>{});
+                if constexpr (RPW > 1) one(IC<RPW - 1>{});
             }
         };
         // MFMAs of a phase with everything else of the phase issued in their shadow, in pinned order (phase_pinned): per
@@ -968,6 +992,7 @@ __global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs 
     constexpr int NPASS = BM / RPE;
     const int c16 = tid % CH, prw = tid / CH;            // 16-byte chunk (8 channels), pixel row slot
     // pass i handles tile pixel prw + RPE i, i.e. RPE / 16 image rows further down per pass: one element offset + a stride
+    static_assert(RPW <= 2, "two rounds per window at most");
     static_assert(RPE % 16 == 0, "a pass advances by whole tile rows");
     const size_t e0 = ((size_t)(b * H + y0 + (prw >> 4)) * Wd + x0 + (prw & 15)) * a.Cout + n0 + c16 * 8;
     const size_t estep = (size_t)(RPE / 16) * Wd * a.Cout;
@@ -1044,7 +1069,7 @@ template <int TH, int NW, int NCO = 128, int SS = 0> constexpr int t32_smem_byte
 template <typename T, int TH, int ABL, int NW = 4, int NCO = 128, int SS = 0>
 int launch_t32_t(const FusedArgs &a, hipStream_t st) {
     constexpr int smem = t32_smem_bytes<TH, NW, NCO, SS>();
-    static_assert(smem <= (SS ? 160 : 80) * 1024, "LDS budget: two workgroups per CU (one with super-steps)");
+    static_assert(smem <= ((SS || TH == 32) ? 160 : 80) * 1024, "LDS budget: two workgroups per CU (one with super-steps / 512-pixel tiles)");
     static bool attr = false;
     if (!attr) {
         BNDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_t32<T, TH, ABL, NW, NCO, SS>),
@@ -1132,6 +1157,8 @@ int launch_conv_t32(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
             return TH == 16 ? launch_t32_t<_Float16, 16, 0, 4, 32>(a, st) : launch_t32_t<_Float16, 8, 0, 4, 32>(a, st);
         return TH == 16 ? launch_t32_t<__bf16, 16, 0, 4, 32>(a, st) : launch_t32_t<__bf16, 8, 0, 4, 32>(a, st);
     }
+    if (TH == 32)    // 512-pixel tiles: one 4-wave workgroup per CU with the whole register file (128 x 128 wave tiles)
+        return dtype == BNDM_DTYPE_F16 ? launch_t32_t<_Float16, 32, 0>(a, st) : launch_t32_t<__bf16, 32, 0>(a, st);
     const long long nblk = (long long)a.B * (a.H / TH) * (a.W / 16) * (a.Cout / 128);
     const int nw = nblk >= 448 ? 4 : 8;
     if (dtype == BNDM_DTYPE_F16) {

@@ -577,8 +577,16 @@ struct Builder {
         // 256-pixel tiles unless that leaves workgroup slots idle at this handle's batch size
         int TH = out.H >= 32 ? 16 : 8;
         const long long tiles16 = (long long)h->cfg.max_batch * (out.H / 16) * (out.W / 16) * (head ? 1 : out.C / 128);
-        static const int th16_min = getenv("BNDM_TH16_MIN") ? atoi(getenv("BNDM_TH16_MIN")) : 192;
+        auto env_int = [](const char *name, int dflt) {
+            const char *e = getenv(name);
+            return e ? atoi(e) : dflt;
+        };
+        static const int th16_min = env_int("BNDM_TH16_MIN", 192);
         if (TH == 16 && tiles16 < th16_min) TH = 8;
+        // 512-pixel tiles (one 4-wave workgroup per CU with 512 registers per lane, 128 x 128 wave tiles): an experiment
+        // of round 4, OFF unless BNDM_TH32_MIN names the smallest grid (in 512-pixel tiles) that should use them
+        static const int th32_min = env_int("BNDM_TH32_MIN", 1 << 30);
+        if (TH == 16 && !head && out.H % 32 == 0 && tiles16 / 2 >= th32_min) TH = 32;
         {
             a.Ktot = Ktot;
             a.out_nchw32 = head ? 1 : 0;
@@ -633,7 +641,7 @@ struct Builder {
             c.stats = pst >= 0 ? (float *)hh->P(pst) : nullptr;
             return launch_conv_t32(hh->dtype(), TH, c, r.st);
         });
-        h->ops[op_index].dominant = TH == 16 && !head;
+        h->ops[op_index].dominant = TH >= 16 && !head;
         h->ops[op_index].kernel = S(head ? "conv_t32<TH=%d,N=32>" : "conv_t32<TH=%d>", TH);
         h->ops[op_index].bytes_per_sample = abytes;
         h->ops[op_index].bytes_fixed = wbytes;

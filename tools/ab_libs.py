@@ -1,6 +1,6 @@
 """Profiling aid: same-box A/B of several builds of the library (interleaved rounds, one subprocess per run).
 
-    python tools/ab_libs.py [--rounds 3] [--acc] [--full] libA.so libB.so ...
+    python tools/ab_libs.py [--rounds 3] [--acc] [--full] libA.so libB.so libB.so@BNDM_TH32_MIN=256 ...
 
 Per library and round: `bench.py --profile-only` (HIP-event per-op profile of the c2 forward, B=64) -> ms per forward, the
 average conv_t32<TH=16> launch, per-family / per-resolution sums.  --acc adds the rel-L2 of the f16 engine against the fp32
@@ -15,8 +15,15 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(lib, extra, dump=None):
-    env = dict(os.environ)
+def split_variant(v):
+    """'path/lib.so@VAR=val,VAR2=val2' -> (path, {VAR: val, ...}): one library under different environment switches"""
+    lib, _, envs = v.partition("@")
+    return os.path.abspath(lib), dict(kv.split("=", 1) for kv in envs.split(",") if kv)
+
+
+def run(variant, extra, dump=None):
+    lib, extra_env = split_variant(variant)
+    env = dict(os.environ, **extra_env)
     if dump:
         env["BNDM_PROFILE_DUMP"] = dump
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_with_lib.py"), lib, "--no-cpu-baseline",
@@ -73,7 +80,7 @@ def main():
         elif a == "--full":
             full = True
         else:
-            libs.append(os.path.abspath(a))
+            libs.append(a)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     res = {l: [] for l in libs}
     for r in range(rounds):
@@ -101,7 +108,9 @@ def main():
         print("   " + "  ".join(f"{k} {v:.3f}" for k, v in top))
     if acc:
         for lib in libs:
-            r = subprocess.run([sys.executable, "-c", ACC % (ROOT, lib)], capture_output=True, text=True, cwd=ROOT)
+            lp, ev = split_variant(lib)
+            r = subprocess.run([sys.executable, "-c", ACC % (ROOT, lp)], capture_output=True, text=True, cwd=ROOT,
+                               env=dict(os.environ, **ev))
             print(f"== {os.path.basename(lib)}: " + (r.stdout.strip().splitlines() or [r.stderr[-500:]])[-1])
 
 
