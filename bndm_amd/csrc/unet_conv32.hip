@@ -84,7 +84,7 @@ struct Chunk {
 // tiles (= one chunk: tap t lives in slot t) filled two super-steps ahead, three patch buffers (the chunk after next is
 // DMA'd while the next one is normalised).  Same MFMA order as the per-tap schedule, i.e. bit-identical results.
 template <typename T, int TH, int ABL, int NW, int NCO, int SS = 0>
-__global__ __launch_bounds__(NW * 64, (SS || TH == 32) ? 1 : 2) void conv_t32(const FusedArgs a, const int tiles_x, const int tps, const int ntn,
+__global__ __launch_bounds__(NW * 64, SS ? 1 : 2) void conv_t32(const FusedArgs a, const int tiles_x, const int tps, const int ntn,
                                                    const int nsteps_w, unsigned *__restrict__ dbg) {
     using v8 = typename TT<T>::v8;
     using v4 = typename TT<T>::v4;
@@ -323,6 +323,24 @@ __global__ __launch_bounds__(NW * 64, (SS || TH == 32) ? 1 : 2) void conv_t32(co
         if (ABL & 4) return;
         fa[i] = *reinterpret_cast<const v8 *>(smem + (wa ^ (ks << 5)) + i * 2048 + (SS ? t * W_BYTES : 0));
     };
+    // one phase: the MFMAs of k16 slice `kcur` (operands in fa, fb[kcur]) and the reads of slice (tnext, knext)
+    auto mma_refill = [&](auto kcur, auto tnext, auto knext) {
+        constexpr int ks = decltype(kcur)::value;
+        read_b(tnext, knext);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            if (ABL & 1) {
+                asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+                for (int j = 0; j < TM; ++j) asm volatile("" ::"v"(fb[ks][j]));
+            } else {
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = TT<T>::mfma(fa[i], fb[ks][j], acc[i][j]);
+            }
+            read_a(tnext, knext, i);
+        }
+    };
+
     // One phase in PINNED order (scheduling fences instead of sched_group_barrier patterns, whose greedy solver bunches
     // the normalisation arithmetic at the head of a phase as soon as its instruction mix changes):
     //     [patch fragment reads]  { [MFMAs of weight tile i] | [its refill read, extra(i)] } x TN
@@ -381,52 +399,14 @@ __global__ __launch_bounds__(NW * 64, (SS || TH == 32) ? 1 : 2) void conv_t32(co
     };
 
     // ---- prologue -------------------------------------------------------------------------------------
-    // A workgroup's life is serial (prologue, K loop, epilogue; the partner workgroup on the CU only fills the gaps), so
-    // the prologue is ordered by its longest dependency chain: the GroupNorm partial sums of this sample are requested
-    // FIRST; the bias row, the patch of chunk 0 and the first weight tiles (all LDS-DMA, retiring in issue order) are
-    // issued in the shadow of that round trip; then sums -> group statistics -> scale/shift table -> chunk 0 normalised.
+    // scale/shift table (one 16-byte piece per thread, zeros past its end), patch of chunk 0, weight tiles of
+    // steps 0..3 -- all by LDS-DMA, so they retire in issue order and one counted wait separates them
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // chunk table visible
     asm volatile("" ::: "memory");
     life(6);
     Chunk cur = load_chunk(0);
     Chunk nxt = cur;
-    const int nstep9 = nchunk9 * 9;
-    // DMAs the prologue issues behind the partial-sum loads (the counted wait for those loads)
-    constexpr int NDMA_PRO = 1 + NROUND + (SS ? 9 * NWP + 3 : 4 * NWP);
-    constexpr int NSUM = 8;                              // partial-sum loads in flight per thread
-    f32x4 psum[NSUM];
-    float gam[2] = {0.f, 0.f}, bet[2] = {0.f, 0.f};      // C <= 512: at most two channels per thread
-    // partial sums [B][slabs][C / 2][2]: (sum, sum of squares) per channel PAIR.  One 16-byte load = two pairs; the
-    // quads of cat(x1, x2) are dealt to the lanes of a slab group, the slabs of a sample to NT / PG slab groups.
-    const int gC = a.ssC, gC1 = a.gn_C1, NQ = gC >> 2;
-    const int PG = (NQ + 63) & ~63, G = NT / (PG > 0 ? PG : 64);
-    const int sg = tid / (PG > 0 ? PG : 64), qd = tid - sg * PG;
-    const bool q_on = a.gn_p1 && qd < NQ && sg < G;
-    const bool q_first = 4 * qd < gC1;
-    const int q_ns = q_first ? a.gn_ns1 : a.gn_ns2;
-    const int k_lo = sg * q_ns / (G > 0 ? G : 1), k_hi = (sg + 1) * q_ns / (G > 0 ? G : 1);
-    if (a.gn_p1) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int c = tid + k * NT;
-            gam[k] = c < gC ? a.gn_gamma[c] : 0.f;
-            bet[k] = c < gC ? a.gn_beta[c] : 0.f;
-        }
-        const float *qp = q_first ? a.gn_p1 : a.gn_p2;
-        const int qCs = q_first ? gC1 : gC - gC1, qq = q_first ? qd : qd - (gC1 >> 2);
-        const int nmax = __builtin_amdgcn_readfirstlane(((a.gn_ns1 > a.gn_ns2 ? a.gn_ns1 : a.gn_ns2) + G - 1) / G);
-#pragma unroll
-        for (int j = 0; j < NSUM; ++j) {
-            psum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (j < nmax) {                              // wave-uniform
-                const bool ok = q_on && k_lo + j < k_hi;
-                const float *ptr = ok ? qp + ((size_t)(b * q_ns + k_lo + j) * (qCs >> 1) + 2 * qq) * 2 : (const float *)a.zeros;
-                // (inline assembly: beside LDS-DMAs the compiler waits vmcnt(0) for an ordinary load's result)
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(psum[j]) : "v"(ptr) : "memory");
-            }
-        }
-    }
     {
         if (!a.gn_p1) {
             const __amdgpu_buffer_rsrc_t srs =
@@ -443,6 +423,7 @@ __global__ __launch_bounds__(NW * 64, (SS || TH == 32) ? 1 : 2) void conv_t32(co
         __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lds_ptr_t)(smem + (w == 0 ? OFF_BIAS : OFF_DUMP)), 16,
                                                  (unsigned)(tid * 16), 0, 0, 0);
     }
+    const int nstep9 = nchunk9 * 9;
     if (nchunk9 > 0) {
         auto issue_all = [&](auto self, auto rc) {
             constexpr int r = decltype(rc)::value;
@@ -475,69 +456,62 @@ __global__ __launch_bounds__(NW * 64, (SS || TH == 32) ? 1 : 2) void conv_t32(co
         }
         life(7);
         if (a.gn_p1) {
-            // GroupNorm(32) statistics of cat(x1, x2) for this sample from the producers' per-tile partial sums: slab order
-            // inside a slab group, slab groups in order, fp64 group combine.  Scratch: the last patch buffer, idle until
-            // the main loop: part[G][C / 2] (sum, sum of squares) per pair and slab group, gst[32] (mean, rstd) per group.
-            float2 *part = reinterpret_cast<float2 *>(smem + (NPB - 1) * PATCH_BYTES);
-            float2 *gst = part + 2 * NT;                           // (G * C / 2 <= 2 NT pairs)
-            static_assert((2 * NT + 32) * 8 <= PATCH_BYTES, "GroupNorm scratch");
-            // the partial sums are back (loads and LDS-DMAs retire in issue order: everything issued behind them may still fly)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA_PRO) : "memory");
-            f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+            // GroupNorm(32) statistics of cat(x1, x2) for this sample from the producers' per-tile partial sums (fixed slab
+            // order, fp64 group combine: the arithmetic of gn_finalize2), while the DMAs above are in flight.  Scratch: the
+            // second patch buffer, idle until the main loop.
+            float *cs = reinterpret_cast<float *>(smem + (NPB - 1) * PATCH_BYTES), *css = cs + 512;
+            const int C = a.ssC, C1 = a.gn_C1;
+            float gam[2], bet[2];                        // C <= 512: at most two channels per thread; loaded up front
 #pragma unroll
-            for (int j = 0; j < NSUM; ++j) {
-                asm volatile("" : "+v"(psum[j]));
-                t4 += psum[j];
+            for (int k = 0; k < 2; ++k) {
+                const int c = tid + k * NT;
+                gam[k] = c < C ? a.gn_gamma[c] : 0.f;
+                bet[k] = c < C ? a.gn_beta[c] : 0.f;
             }
-            {   // (more than NSUM slabs per group: the rest synchronously; not a case of the reference networks)
-                const float *qp = q_first ? a.gn_p1 : a.gn_p2;
-                const int qCs = q_first ? gC1 : gC - gC1, qq = q_first ? qd : qd - (gC1 >> 2);
-                for (int k = k_lo + NSUM; q_on && k < k_hi; ++k)
-                    t4 += *reinterpret_cast<const f32x4 *>(qp + ((size_t)(b * q_ns + k) * (qCs >> 1) + 2 * qq) * 2);
-            }
-            if (q_on) {
-                part[sg * (gC >> 1) + 2 * qd] = float2{t4[0], t4[1]};
-                part[sg * (gC >> 1) + 2 * qd + 1] = float2{t4[2], t4[3]};
+            for (int c = tid; c < C; c += NT) {
+                const bool first = c < C1;
+                const float *p = first ? a.gn_p1 : a.gn_p2;
+                const int ns = first ? a.gn_ns1 : a.gn_ns2, Cs = first ? C1 : C - C1, cc = first ? c : c - C1;
+                float s = 0.f, q2 = 0.f;
+                for (int k0 = 0; k0 < ns; k0 += 16) {        // 16 slabs in flight; the sums keep the slab order
+                    float2 v[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        v[k] = k0 + k < ns ? *reinterpret_cast<const float2 *>(p + ((size_t)(b * ns + k0 + k) * Cs + cc) * 2)
+                                           : float2{0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        s += v[k].x;
+                        q2 += v[k].y;
+                    }
+                }
+                cs[c] = s;
+                css[c] = q2;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             life(8);
-            const int Cg = gC >> 5, Pg = Cg >> 1;                 // channels / pairs per group (Cg is even: conv_t32_supports)
-            if (tid < 256) {
-                // eight lanes per group: the G * Pg partial sums of a group dealt round-robin, then a fixed butterfly (one
-                // thread per group walking them serially was ~2 K clocks of dependent LDS latency with eight waves waiting)
-                const int g = tid >> 3, jl = tid & 7, nitem = G * Pg;
-                double s = 0, q2 = 0;
-                for (int e = jl; e < nitem; e += 8) {
-                    const int g2 = e / Pg, k = e - g2 * Pg;
-                    const float2 v = part[g2 * (gC >> 1) + g * Pg + k];
-                    s += v.x;
-                    q2 += v.y;
-                }
+            const int Cg = C >> 5;
+            float *ssW = reinterpret_cast<float *>(smem + OFF_SS);
 #pragma unroll
-                for (int m = 1; m < 8; m <<= 1) {
-                    s += __shfl_xor(s, m);
-                    q2 += __shfl_xor(q2, m);
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const int c = tid + k2 * NT;
+                if (c >= C) break;
+                const int g0 = (c / Cg) * Cg;
+                double s = 0, q2 = 0;
+                for (int k = 0; k < Cg; ++k) {
+                    s += cs[g0 + k];
+                    q2 += css[g0 + k];
                 }
                 const double n = (double)Cg * a.gn_HW;
                 const double mean = s / n;
                 double var = q2 / n - mean * mean;
                 var = var > 0 ? var : 0;
-                if (jl == 0) gst[g] = float2{(float)mean, (float)(1.0 / sqrt(var + (double)a.gn_eps))};
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            float *ssW = reinterpret_cast<float *>(smem + OFF_SS);
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                const int c = tid + k2 * NT;
-                if (c >= gC) break;
-                const float2 ms = gst[c / Cg];
-                const float sc = ms.y * gam[k2];
+                const float rstd = (float)(1.0 / sqrt(var + (double)a.gn_eps));
+                const float sc = rstd * gam[k2];
                 ssW[c] = T32_LOG2E * sc;                                   // (norm2: the table carries log2(e))
-                ssW[gC + c] = T32_LOG2E * (bet[k2] - ms.x * sc);
+                ssW[C + c] = T32_LOG2E * (bet[k2] - (float)mean * sc);
             }
         }
         life(9);
@@ -596,66 +570,51 @@ __global__ __launch_bounds__(NW * 64, (SS || TH == 32) ? 1 : 2) void conv_t32(co
 #pragma unroll
         for (int i = 0; i < TN; ++i) read_a(IC<0>{}, IC<0>{}, i);
     }
-    // Normalisation windows: round r rides behind the MFMAs of window s = W0 + r (second phase of step s, first phase of
-    // step s+1).  A partial last round (only the first NREMW waves own pieces of it) gets a window of its own -- done in
-    // one go at the end of the last window it kept the other waves waiting at B_8 for ~600 clocks per chunk.
-    constexpr bool PARTIAL = NREMW < NW;
-    constexpr int RPW = NROUND > 6 ? 2 : 1;                // rounds per window (the 512-pixel tile has ten rounds)
-    constexpr int NWIN = (NROUND + RPW - 1) / RPW;
-    constexpr int W0 = (PARTIAL || RPW > 1) ? 8 - NWIN : 3;
-    static_assert(W0 >= 2 && W0 + NWIN <= 8, "normalisation schedule: RPW rounds per window of steps W0..7");
+    constexpr int NFULL = NROUND - (NREMW < NW ? 1 : 0);   // rounds in which every wave owns pieces
+    static_assert(NFULL <= 5, "normalisation schedule: one full round per window of steps 3..7 (+ a partial one)");
     auto chunk_body = [&](auto doxc, const int c) __attribute__((always_inline)) {
         constexpr bool DOX = decltype(doxc)::value != 0 && !(ABL & 8) && !(ABL & 16);
-        u32x4 xa[RPW];                                         // rounds in flight
-        f32x4 sa[RPW], ha[RPW];
-        float ny[RPW][4], ne[RPW][4];
-#pragma unroll
-        for (int q = 0; q < RPW; ++q) {
-            xa[q] = u32x4{0u, 0u, 0u, 0u};
-            sa[q] = ha[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) ny[q][k] = ne[q][k] = 0.f;
-        }
-        // window of step s (W0..7): position 0 = second phase of step s, position 1 = first phase of step s+1; it
-        // normalises rounds RPW (s - W0) .. + RPW - 1, four channels of each per position
+        u32x4 xa = {0u, 0u, 0u, 0u};                           // round in flight
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, ha = {0.f, 0.f, 0.f, 0.f};
+        // window of step s (3..7): position 0 = second phase of step s, position 1 = first phase of step s+1; it
+        // normalises full round s-3, four channels per position
         // xf_pre: LDS reads of a position, issued at the end of the phase before it (they return during the barrier wait)
         auto xf_pre = [&](auto sc, auto pc) {
             constexpr int s = decltype(sc)::value, p = decltype(pc)::value;
-            constexpr int r0 = s >= W0 && s <= 7 && RPW * (s - W0) < NROUND ? RPW * (s - W0) : -1;
-            if constexpr (DOX && r0 >= 0) {
-                constexpr int rl = r0 + RPW - 1 < NROUND ? r0 + RPW - 1 : NROUND - 1;     // last round of the window
-                // own pieces landed?  (G_s is issued later in this phase: count up to G_(s-1); rounds retire in order)
-                if constexpr (p == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dmas_after_round(NROUND, NWP, rl, s - 1)) : "memory");
-                auto one = [&](auto qc) {
-                    constexpr int q = decltype(qc)::value, r = r0 + q;
-                    if constexpr (r < NROUND) {
-                        if (xf_owner(r)) {                       // (wave-uniform; constant for all but a partial last round)
-                            if constexpr (p == 0) xf_begin(IC<r>{}, pbuf ^ 1, xa[q]);
-                            const float *sc4 = ssL + nxt.ssbase + piece_of(r).lc * 8 + 4 * p;
-                            sa[q] = *reinterpret_cast<const f32x4 *>(sc4);
-                            ha[q] = *reinterpret_cast<const f32x4 *>(sc4 + a.ssC);
-                        }
-                    }
-                };
-                one(IC<0>{});
-                if constexpr (RPW > 1) one(IC<RPW - 1>{});
+            constexpr int r = s >= 3 && s <= 7 && s - 3 < NFULL ? s - 3 : -1;
+            if constexpr (DOX && r >= 0) {
+                if constexpr (p == 0) {
+                    // own piece landed?  (G_s is issued later in this phase: count up to G_(s-1))
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dmas_after_round(NROUND, NWP, r, s - 1)) : "memory");
+                    xf_begin(IC<r>{}, pbuf ^ 1, xa);
+                }
+                const float *sc4 = ssL + nxt.ssbase + piece_of(r).lc * 8 + 4 * p;
+                sa = *reinterpret_cast<const f32x4 *>(sc4);
+                ha = *reinterpret_cast<const f32x4 *>(sc4 + a.ssC);
             }
         };
+        float ny[4] = {0.f, 0.f, 0.f, 0.f}, ne[4] = {0.f, 0.f, 0.f, 0.f};
         auto xf_math = [&](auto sc, auto pc, auto ic) {          // stage ic of the window position (s, p)
             constexpr int s = decltype(sc)::value, p = decltype(pc)::value, i = decltype(ic)::value;
-            constexpr int r0 = s >= W0 && s <= 7 && RPW * (s - W0) < NROUND ? RPW * (s - W0) : -1;
-            if constexpr (DOX && r0 >= 0) {
-                auto one = [&](auto qc) {
-                    constexpr int q = decltype(qc)::value, r = r0 + q;
-                    if constexpr (r < NROUND) {
-                        if (xf_owner(r)) {
-                            norm_stage(ic, pc, xa[q], sa[q], ha[q], ny[q], ne[q]);
-                            if constexpr (p == 1 && i == STG_C) xf_end(IC<r>{}, pbuf ^ 1, xa[q]);
-                        }
-                    }
-                };
-                one(IC<0>{});
-                if constexpr (RPW > 1) one(IC<RPW - 1>{});
+            constexpr int r = s >= 3 && s <= 7 && s - 3 < NFULL ? s - 3 : -1;
+            if constexpr (DOX && r >= 0) {
+                norm_stage(ic, pc, xa, sa, ha, ny, ne);
+                if constexpr (p == 1 && i == STG_C) xf_end(IC<r>{}, pbuf ^ 1, xa);
+            }
+        };
+        // the partial last round (pieces of waves < NREMW only): in one go at the end of the last window (the
+        // registers of the finished round are free again)
+        auto xf_tail = [&](auto sc, auto pc) {
+            constexpr int s = decltype(sc)::value, p = decltype(pc)::value;
+            if constexpr (DOX && NREMW < NW && s == 7 && p == 1) {
+                constexpr int r = NROUND - 1;
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dmas_after_round(NROUND, NWP, r, s)) : "memory");
+                if (w < NREMW) {
+                    xf_begin(IC<r>{}, pbuf ^ 1, xa);
+                    xf_half(IC<r>{}, IC<0>{}, nxt, xa);
+                    xf_half(IC<r>{}, IC<1>{}, nxt, xa);
+                    xf_end(IC<r>{}, pbuf ^ 1, xa);
+                }
             }
         };
         // MFMAs of a phase with everything else of the phase issued in their shadow, in pinned order (phase_pinned): per
@@ -687,6 +646,7 @@ __global__ __launch_bounds__(NW * 64, (SS || TH == 32) ? 1 : 2) void conv_t32(co
             // first phase: MFMAs of (tap t, k 0..15); reads of (tap t, k 16..31); then the LDS reads of the normalisation
             // slice that rides under the second phase, so that they return during the wait / barrier
             phase(IC<0>{}, tc, IC<1>{}, IC<t - 1>{}, IC<1>{}, no_dma);
+            xf_tail(IC<t - 1>{}, IC<1>{});
             xf_pre(tc, IC<0>{});
             // advance the weight ring (and, at the last tap, the chunk) before the reads of the next step
             {
@@ -983,16 +943,11 @@ __global__ __launch_bounds__(NW * 64, (SS || TH == 32) ? 1 : 2) void conv_t32(co
     __syncthreads();
     life(4);
 
-    // ---- epilogue 2: residual (row-coalesced 16-B reads) + full-row stores + statistics per channel PAIR ------------
-    // The pass is VALU-light on purpose (a workgroup's epilogue is serial time): the residual is added as packed 16-bit
-    // pairs, and the GroupNorm partial sums are taken per pair of adjacent channels by v_dot2 (x . (1, 1) and x . x,
-    // fp32 accumulation): 3 issues per dword instead of 10.  Every consuming GroupNorm has groups of an even number of
-    // channels, so pair sums lose nothing -- and the consumers' prologues read half the bytes.
+    // ---- epilogue 2: residual (row-coalesced 16-B reads) + full-row stores + per-channel statistics ------
     constexpr int RPE = NT / CH;                         // pixel rows handled per pass
     constexpr int NPASS = BM / RPE;
     const int c16 = tid % CH, prw = tid / CH;            // 16-byte chunk (8 channels), pixel row slot
     // pass i handles tile pixel prw + RPE i, i.e. RPE / 16 image rows further down per pass: one element offset + a stride
-    static_assert(RPW <= 2, "two rounds per window at most");
     static_assert(RPE % 16 == 0, "a pass advances by whole tile rows");
     const size_t e0 = ((size_t)(b * H + y0 + (prw >> 4)) * Wd + x0 + (prw & 15)) * a.Cout + n0 + c16 * 8;
     const size_t estep = (size_t)(RPE / 16) * Wd * a.Cout;
@@ -1001,32 +956,29 @@ __global__ __launch_bounds__(NW * 64, (SS || TH == 32) ? 1 : 2) void conv_t32(co
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) rres[i] = *reinterpret_cast<const v8 *>((const T *)a.resid + e0 + i * estep);
     }
-    auto dot2 = [](unsigned x, unsigned y, float acc) {
-        if constexpr (std::is_same<T, _Float16>::value)
-            return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, x), __builtin_bit_cast(v2, y), acc, false);
-        else return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, x), __builtin_bit_cast(v2, y), acc, false);
-    };
-    constexpr unsigned ONES = std::is_same<T, _Float16>::value ? 0x3c003c00u : 0x3f803f80u;
-    float s1[4], s2[4];
+    float s1[8], s2[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) s1[e] = s2[e] = 0.f;
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
         const int pl = prw + RPE * i;
-        v8 vt = *reinterpret_cast<const v8 *>(stg + pl * RB + ((c16 ^ skey(pl)) << 4));
-        if (a.resid) vt = vt + rres[i];                      // (16-bit add: packed pairs for f16)
-        const u32x4 v = __builtin_bit_cast(u32x4, vt);
-        store_wt(reinterpret_cast<v8 *>((T *)a.out + e0 + i * estep), vt);
+        v8 v = *reinterpret_cast<const v8 *>(stg + pl * RB + ((c16 ^ skey(pl)) << 4));
+        if (a.resid) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            s1[e] = dot2(v[e], ONES, s1[e]);
-            s2[e] = dot2(v[e], v[e], s2[e]);
+            for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] + (float)rres[i][e]);
+        }
+        store_wt(reinterpret_cast<v8 *>((T *)a.out + e0 + i * estep), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = (float)v[e];
+            s1[e] += f;
+            s2[e] = fmaf(f, f, s2[e]);
         }
     }
     if (a.stats) {
         // the row slots of a wave (lanes with equal l % CH) in a fixed order, then the waves through LDS
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 8; ++e) {
             if constexpr (CH == 8) {
                 s1[e] += __shfl_xor(s1[e], 8);
                 s2[e] += __shfl_xor(s2[e], 8);
@@ -1036,20 +988,20 @@ __global__ __launch_bounds__(NW * 64, (SS || TH == 32) ? 1 : 2) void conv_t32(co
             s1[e] += __shfl_xor(s1[e], 32);
             s2[e] += __shfl_xor(s2[e], 32);
         }
-        float *red = reinterpret_cast<float *>(smem + BM * RB);            // [NW waves][NCO / 2 pairs][2]
+        float *red = reinterpret_cast<float *>(smem + BM * RB);            // [NW waves][NCO][2]
         if (l < CH) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                red[((w * (NCO / 2)) + c16 * 4 + e) * 2 + 0] = s1[e];
-                red[((w * (NCO / 2)) + c16 * 4 + e) * 2 + 1] = s2[e];
+            for (int e = 0; e < 8; ++e) {
+                red[((w * NCO) + c16 * 8 + e) * 2 + 0] = s1[e];
+                red[((w * NCO) + c16 * 8 + e) * 2 + 1] = s2[e];
             }
         }
         __syncthreads();
-        if (tid < NCO) {
+        if (tid < 2 * NCO) {
             float t = 0.f;
 #pragma unroll
-            for (int wv = 0; wv < NW; ++wv) t += red[wv * NCO + tid];
-            store_wt(a.stats + ((size_t)(b * tps + tin) * (a.Cout >> 1) + (n0 >> 1)) * 2 + tid, t);
+            for (int wv = 0; wv < NW; ++wv) t += red[wv * 2 * NCO + tid];
+            store_wt(a.stats + ((size_t)(b * tps + tin) * a.Cout + n0) * 2 + tid, t);
         }
     }
     life(5);
@@ -1069,7 +1021,7 @@ template <int TH, int NW, int NCO = 128, int SS = 0> constexpr int t32_smem_byte
 template <typename T, int TH, int ABL, int NW = 4, int NCO = 128, int SS = 0>
 int launch_t32_t(const FusedArgs &a, hipStream_t st) {
     constexpr int smem = t32_smem_bytes<TH, NW, NCO, SS>();
-    static_assert(smem <= ((SS || TH == 32) ? 160 : 80) * 1024, "LDS budget: two workgroups per CU (one with super-steps / 512-pixel tiles)");
+    static_assert(smem <= (SS ? 160 : 80) * 1024, "LDS budget: two workgroups per CU (one with super-steps)");
     static bool attr = false;
     if (!attr) {
         BNDM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_t32<T, TH, ABL, NW, NCO, SS>),
@@ -1113,7 +1065,6 @@ bool conv_t32_supports(const FusedArgs &a) {
         if ((long long)a.B * px * a.seg[i].C * 2 >= (1LL << 31)) return false;
     }
     if (a.ss && 2 * a.ssC * 4 > T32_SS_BYTES) return false;
-    if (a.ssC % 64) return false;                      // statistics per channel pair: groups of an even number of channels
     return a.nseg >= 1 && a.seg[0].taps == 9 && nchunks <= T32_MAX_CHUNKS && a.W % 16 == 0 &&
            (a.out_nchw32 ? a.Cout <= 32 && !a.resid && !a.stats && !a.temb
                          : a.Cout % 128 == 0);
@@ -1157,8 +1108,6 @@ int launch_conv_t32(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
             return TH == 16 ? launch_t32_t<_Float16, 16, 0, 4, 32>(a, st) : launch_t32_t<_Float16, 8, 0, 4, 32>(a, st);
         return TH == 16 ? launch_t32_t<__bf16, 16, 0, 4, 32>(a, st) : launch_t32_t<__bf16, 8, 0, 4, 32>(a, st);
     }
-    if (TH == 32)    // 512-pixel tiles: one 4-wave workgroup per CU with the whole register file (128 x 128 wave tiles)
-        return dtype == BNDM_DTYPE_F16 ? launch_t32_t<_Float16, 32, 0>(a, st) : launch_t32_t<__bf16, 32, 0>(a, st);
     const long long nblk = (long long)a.B * (a.H / TH) * (a.W / 16) * (a.Cout / 128);
     const int nw = nblk >= 448 ? 4 : 8;
     if (dtype == BNDM_DTYPE_F16) {

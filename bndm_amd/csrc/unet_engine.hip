@@ -365,7 +365,7 @@ int pack_conv_weight(bndm_unet *h, const std::vector<WSeg> &segs, int Cout, int 
 // graph construction
 // ------------------------------------------------------------------------------------------------
 struct StatRef {
-    int pslot = -1;   // buffer slot of partial sums [B][nslab][C / 2][2] (per channel pair)
+    int pslot = -1;   // buffer slot of partial sums [B][nslab][C][2]
     int nslab = 0;
 };
 
@@ -411,7 +411,7 @@ struct Builder {
         if (it != stats_of.end()) return it->second;
         bndm_unet *hh = h;
         const int HW = x.H * x.W, nslab = gn_num_slabs(HW), C = x.C;
-        StatRef sr{h->new_slot((size_t)h->cfg.max_batch * nslab * (C / 2) * 2 * 4), nslab};
+        StatRef sr{h->new_slot((size_t)h->cfg.max_batch * nslab * C * 2 * 4), nslab};
         const int sx = x.slot, sp = sr.pslot;
         cur_name = S("gnst %-44s C=%-4d %dx%d", "", C, x.H, x.W);
         push(OPC_OTHER, 0, [=](RunCtx &r) {
@@ -421,7 +421,7 @@ struct Builder {
         return sr;
     }
     StatRef new_stats(const Act &x, int nslab) {
-        StatRef sr{h->new_slot((size_t)h->cfg.max_batch * nslab * (x.C / 2) * 2 * 4), nslab};
+        StatRef sr{h->new_slot((size_t)h->cfg.max_batch * nslab * x.C * 2 * 4), nslab};
         stats_of[x.slot] = sr;
         return sr;
     }
@@ -441,11 +441,6 @@ struct Builder {
         bndm_unet *hh = h;
         GnSpec g;
         const int C1 = x1.C, C2 = x2 ? x2->C : 0, C = C1 + C2, HW = x1.H * x1.W;
-        if (C % (2 * GROUPS) || C1 % 2 || C2 % 2) {       // the partial sums are per channel pair
-            set_error("GroupNorm %s: %d+%d channels -- groups must have an even number of channels", pname.c_str(), C1, C2);
-            rc = BNDM_E_ARG;
-            return g;
-        }
         const StatRef a1 = ensure_stats(x1);
         const StatRef a2 = x2 ? ensure_stats(*x2) : StatRef{};
         const float *gamma, *beta;
@@ -577,16 +572,8 @@ struct Builder {
         // 256-pixel tiles unless that leaves workgroup slots idle at this handle's batch size
         int TH = out.H >= 32 ? 16 : 8;
         const long long tiles16 = (long long)h->cfg.max_batch * (out.H / 16) * (out.W / 16) * (head ? 1 : out.C / 128);
-        auto env_int = [](const char *name, int dflt) {
-            const char *e = getenv(name);
-            return e ? atoi(e) : dflt;
-        };
-        static const int th16_min = env_int("BNDM_TH16_MIN", 192);
+        static const int th16_min = getenv("BNDM_TH16_MIN") ? atoi(getenv("BNDM_TH16_MIN")) : 192;
         if (TH == 16 && tiles16 < th16_min) TH = 8;
-        // 512-pixel tiles (one 4-wave workgroup per CU with 512 registers per lane, 128 x 128 wave tiles): an experiment
-        // of round 4, OFF unless BNDM_TH32_MIN names the smallest grid (in 512-pixel tiles) that should use them
-        static const int th32_min = env_int("BNDM_TH32_MIN", 1 << 30);
-        if (TH == 16 && !head && out.H % 32 == 0 && tiles16 / 2 >= th32_min) TH = 32;
         {
             a.Ktot = Ktot;
             a.out_nchw32 = head ? 1 : 0;
@@ -641,7 +628,7 @@ struct Builder {
             c.stats = pst >= 0 ? (float *)hh->P(pst) : nullptr;
             return launch_conv_t32(hh->dtype(), TH, c, r.st);
         });
-        h->ops[op_index].dominant = TH >= 16 && !head;
+        h->ops[op_index].dominant = TH == 16 && !head;
         h->ops[op_index].kernel = S(head ? "conv_t32<TH=%d,N=32>" : "conv_t32<TH=%d>", TH);
         h->ops[op_index].bytes_per_sample = abytes;
         h->ops[op_index].bytes_fixed = wbytes;

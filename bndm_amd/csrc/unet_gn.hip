@@ -9,27 +9,26 @@
 namespace bndm {
 namespace {
 
-// cat(x1, x2) statistics from per-tensor partial sums (per channel pair: [B][slabs][C / 2][2]); a block owns 4 groups of
-// one sample: grid (8, B)
+// cat(x1, x2) statistics from per-tensor partial sums; a block owns 4 groups of one sample: grid (8, B)
 __global__ __launch_bounds__(128) void gn_finalize2_kernel(const float *__restrict__ p1, int nslab1, int C1,
                                                            const float *__restrict__ p2, int nslab2, int C2, int HW,
                                                            int groups, float eps, const float *__restrict__ gamma,
                                                            const float *__restrict__ beta,
                                                            float *__restrict__ scale_shift) {
-    __shared__ float cs[128], css[128];                   // per channel pair of this block's C / 8 channels
-    const int sub = blockIdx.x, b = blockIdx.y, C = C1 + C2, Cb = C >> 3, Pb = Cb >> 1;
-    for (int pl = threadIdx.x; pl < Pb; pl += blockDim.x) {
-        const int c = 2 * (sub * Pb + pl);                // first channel of the pair
+    __shared__ float cs[256], css[256];
+    const int sub = blockIdx.x, b = blockIdx.y, C = C1 + C2, Cb = C >> 3;
+    for (int cl = threadIdx.x; cl < Cb; cl += blockDim.x) {
+        const int c = sub * Cb + cl;
         const float *p;
-        int ns, Ps, pp;
-        if (c < C1) { p = p1; ns = nslab1; Ps = C1 >> 1; pp = c >> 1; } else { p = p2; ns = nslab2; Ps = C2 >> 1; pp = (c - C1) >> 1; }
+        int ns, Cs, cc;
+        if (c < C1) { p = p1; ns = nslab1; Cs = C1; cc = c; } else { p = p2; ns = nslab2; Cs = C2; cc = c - C1; }
         // loads in batches of 8 (independent, in flight together); the sums keep the slab order
         float s = 0, q = 0;
         for (int k0 = 0; k0 < ns; k0 += 8) {
             float2 v[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                if (k0 + k < ns) v[k] = *reinterpret_cast<const float2 *>(p + ((size_t)(b * ns + k0 + k) * Ps + pp) * 2);
+                if (k0 + k < ns) v[k] = *reinterpret_cast<const float2 *>(p + ((size_t)(b * ns + k0 + k) * Cs + cc) * 2);
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 if (k0 + k < ns) {
@@ -37,15 +36,15 @@ __global__ __launch_bounds__(128) void gn_finalize2_kernel(const float *__restri
                     q += v[k].y;
                 }
         }
-        cs[pl] = s;
-        css[pl] = q;
+        cs[cl] = s;
+        css[cl] = q;
     }
     __syncthreads();
-    const int Cg = C / groups, Pg = Cg >> 1;
+    const int Cg = C / groups;
     for (int cl = threadIdx.x; cl < Cb; cl += blockDim.x) {
-        const int g0 = (cl / Cg) * Pg, c = sub * Cb + cl;
+        const int g0 = (cl / Cg) * Cg, c = sub * Cb + cl;
         double s = 0, q = 0;
-        for (int k = 0; k < Pg; ++k) {
+        for (int k = 0; k < Cg; ++k) {
             s += cs[g0 + k];
             q += css[g0 + k];
         }

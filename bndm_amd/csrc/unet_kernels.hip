@@ -528,20 +528,20 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float *__restrict__ 
             s2[e] = fmaf(f, f, s2[e]);
         }
     }
-    if (stats) {                                                       // per channel PAIR (unet_kernels.hpp: FusedArgs::stats)
-        float *red = reinterpret_cast<float *>(smem + 128 * rowB);     // [RP][C0 / 2][2]
+    if (stats) {
+        float *red = reinterpret_cast<float *>(smem + 128 * rowB);     // [RP][C0][2]
         if (prw < RP)                                                  // (256 % CH != 0 would leave spare threads)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            red[((prw * (C0 >> 1)) + c16 * 4 + e) * 2 + 0] = s1[2 * e] + s1[2 * e + 1];
-            red[((prw * (C0 >> 1)) + c16 * 4 + e) * 2 + 1] = s2[2 * e] + s2[2 * e + 1];
+        for (int e = 0; e < 8; ++e) {
+            red[((prw * C0) + c16 * 8 + e) * 2 + 0] = s1[e];
+            red[((prw * C0) + c16 * 8 + e) * 2 + 1] = s2[e];
         }
         __syncthreads();
         const int nslab = HW >> 7, b0 = m0 >> (logW + logH), slab = (m0 & (HW - 1)) >> 7;
-        for (int i = tid; i < C0; i += 256) {
+        for (int i = tid; i < 2 * C0; i += 256) {
             float t = 0.f;
-            for (int r = 0; r < RP; ++r) t += red[r * C0 + i];
-            store_wt(stats + ((size_t)(b0 * nslab + slab) * (C0 >> 1)) * 2 + i, t);
+            for (int r = 0; r < RP; ++r) t += red[r * C0 * 2 + i];
+            store_wt(stats + ((size_t)(b0 * nslab + slab) * C0) * 2 + i, t);
         }
     }
 }
@@ -549,8 +549,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 // GroupNorm
 // ------------------------------------------------------------------------------------------------
-// partial[((b*nslab + slab)*(C/2) + p)*2 + {0,1}] = sum / sum of squares over the slab's pixels and the channel pair
-// (2p, 2p + 1) -- the granule of every GroupNorm partial sum in this library (groups have an even number of channels)
+// partial[((b*nslab + slab)*C + c)*2 + {0,1}] = sum / sum of squares over the slab's pixels
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T *__restrict__ x1, int C1, const T *__restrict__ x2,
                                                        int C2, int HW, float *__restrict__ partial, int nslab) {
@@ -592,11 +591,11 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T *__restrict__ x1,
                 s[e] += red[(r * CH + tid) * 16 + e];
                 ss[e] += red[(r * CH + tid) * 16 + 8 + e];
             }
-        float *o = partial + ((size_t)(b * nslab + slab) * (C >> 1) + tid * 4) * 2;
+        float *o = partial + ((size_t)(b * nslab + slab) * C + tid * 8) * 2;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            o[2 * e] = s[2 * e] + s[2 * e + 1];
-            o[2 * e + 1] = ss[2 * e] + ss[2 * e + 1];
+        for (int e = 0; e < 8; ++e) {
+            o[2 * e] = s[e];
+            o[2 * e + 1] = ss[e];
         }
     }
 }
@@ -606,12 +605,12 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
                                                           const float *__restrict__ gamma,
                                                           const float *__restrict__ beta,
                                                           float *__restrict__ scale_shift) {
-    __shared__ double cs[512], css[512];                 // per channel pair
-    const int b = blockIdx.x, P = C >> 1;
-    for (int c = threadIdx.x; c < P; c += blockDim.x) {
+    __shared__ double cs[1024], css[1024];
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
         double s = 0, q = 0;
         for (int k = 0; k < nslab; ++k) {
-            const float *p = partial + ((size_t)(b * nslab + k) * P + c) * 2;
+            const float *p = partial + ((size_t)(b * nslab + k) * C + c) * 2;
             s += p[0];
             q += p[1];
         }
@@ -619,11 +618,11 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
         css[c] = q;
     }
     __syncthreads();
-    const int Cg = C / groups, Pg = Cg >> 1;
+    const int Cg = C / groups;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int g0 = (c / Cg) * Pg;
+        const int g0 = (c / Cg) * Cg;
         double s = 0, q = 0;
-        for (int k = 0; k < Pg; ++k) {
+        for (int k = 0; k < Cg; ++k) {
             s += cs[g0 + k];
             q += css[g0 + k];
         }

@@ -55,7 +55,7 @@ int launch_splitk_reduce(int dtype, const float *part, int splitk, const ConvArg
 
 // conv_in: fp32 NCHW sample (+ optional extra fp32 NCHW tensor concatenated on channels) -> NHWC 16-bit
 // W16 is [C0][KP] 16-bit with k = ci*9 + ky*3 + kx, zero-padded to KP (multiple of 16, <= 64)
-// stats (optional): GroupNorm partial sums [B][H*W/128][C0/2][2] (per channel pair) of the stored values
+// stats (optional): GroupNorm partial sums [B][H*W/128][C0][2] of the stored values
 int launch_conv_in(int dtype, const float *x, int Cx, const float *extra, int Ce, const void *W16,
                    const float *bias, void *out, float *stats, int B, int H, int W, int C0, int KP, hipStream_t st);
 
@@ -118,13 +118,12 @@ struct FusedArgs {
     void *out;           // NHWC 16-bit; fp32 NCHW [B][Cout][H][W] when out_nchw32
     int out_nchw32;      // 1: network head (Cout <= 32, no residual / statistics / time embedding)
     int nco;             // output channels per workgroup tile (128)
-    float *stats;        // [B][tiles_per_sample][Cout/2][2] or nullptr: (sum, sum of squares) per tile and channel PAIR
+    float *stats;        // [B][tiles_per_sample][Cout][2] or nullptr
     int B, H, W, Cout;
     const void *zeros;   // >= 16 bytes of zeros
     // In-kernel GroupNorm finalisation (gn_p1 != nullptr; `ss` is then ignored): every workgroup turns the per-tile
     // partial sums of its sample into the scale / shift table itself, in its prologue -- no gn_finalize2 launch.
-    // gn_p1 / gn_p2: [B][gn_ns1 / gn_ns2][(gn_C1 | ssC - gn_C1) / 2][2] (sum, sum of squares per channel pair); at most
-    // 32 slabs each.
+    // gn_p1 / gn_p2: [B][gn_ns1 / gn_ns2][gn_C1 / ssC - gn_C1][2] (sum, sum of squares); at most 32 slabs each.
     const float *gn_p1, *gn_p2, *gn_gamma, *gn_beta;
     int gn_ns1, gn_ns2, gn_C1, gn_HW;
     float gn_eps;
