@@ -1,0 +1,12 @@
+#!/bin/bash
+# Builds the candidate libraries of tools/next_gpu_session.sh from the patches under tools/experiments/ WITHOUT touching the
+# product sources (works in a scratch copy of bndm_amd/csrc):  tools/lib_v6.so (pair-granular GroupNorm sums + sums-first
+# prologue + TH=32 path, = the round-4 patch), tools/lib_v8.so (the same library, TH=32 selected by BNDM_TH32_MIN at run time),
+# tools/lib_v7.so (+ scalar chunk descriptors).
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd); T=$(mktemp -d); mkdir -p $T/bndm_amd $T/include
+cp -r $R/bndm_amd/csrc $T/bndm_amd/; cp $R/include/*.h $T/include/
+cd $T && git init -q . && git apply $R/tools/experiments/round4_pairstats_sumsfirst_th32.patch
+make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v8.so && cp bndm_amd/libbndm_hip.so $R/tools/lib_v6.so
+git apply $R/tools/experiments/conv_t32_scalar_chunks.patch && make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v7.so
+rm -rf $T; ls -la $R/tools/lib_v[678].so
