@@ -148,7 +148,7 @@ def self_launch(args, argv):
 # -------------------------------------------------------------------------------------------------
 # workloads
 # -------------------------------------------------------------------------------------------------
-def make_workload(name, B, N, dtype, dev, rank=0, world=1):
+def make_workload(name, B, N, dtype, dev, rank=0, world=1, lanes=1):
     """-> dict(one_pass, model, res, cin, cout, images_per_pass, metric, workload, extra_stage)
 
     c4 on more than one GPU is the named configuration "batch = world x 32 sharded": the 128-px blue-noise branch permutes
@@ -169,7 +169,7 @@ def make_workload(name, B, N, dtype, dev, rank=0, world=1):
         N = N or 250
         tau = 1000.0 if name == "c2" else 0.2
         L = torch.from_numpy(blue_noise_factor("blue")).to(dev)
-        model = get_model(3, 6, res, dtype=dtype, seed=0).to(dev).eval()
+        model = get_model(3, 6, res, dtype=dtype, seed=0, lanes=lanes).to(dev).eval()
         params = torch.tensor([tau, 0.0, 3.0], device=dev)
         sharded = name == "c4" and world > 1
         BG = B * world if sharded else B                                              # batch the noise branch sees
@@ -203,7 +203,7 @@ def make_workload(name, B, N, dtype, dev, rank=0, world=1):
     if name == "c3":
         from bndm_amd.schedulers import DDIMScheduler
         B, N = B or 64, N or 100
-        model = get_model(3, 3, 64, dtype=dtype, seed=0).to(dev).eval()
+        model = get_model(3, 3, 64, dtype=dtype, seed=0, lanes=lanes).to(dev).eval()
         sch = DDIMScheduler(num_train_timesteps=1000, beta_schedule="linear")
         sch.set_timesteps(N)
 
@@ -223,7 +223,7 @@ def make_workload(name, B, N, dtype, dev, rank=0, world=1):
         model = UNet2DModel(sample_size=64, in_channels=4, out_channels=8, layers_per_block=2, block_out_channels=boc,
                             down_block_types=tuple("AttnDownBlock2D" if i == 4 else "DownBlock2D" for i in range(6)),
                             up_block_types=tuple("AttnUpBlock2D" if i == 1 else "UpBlock2D" for i in range(6)),
-                            dtype=dtype, seed=0).to(dev).eval()
+                            dtype=dtype, seed=0, lanes=lanes).to(dev).eval()
         vae = AutoencoderKL(dtype=dtype).to(dev).eval()
         sch = IADBScheduler(noise_type="gaussianBN", out_channels=8)
         sch.set_timesteps(N)
@@ -243,14 +243,14 @@ def make_workload(name, B, N, dtype, dev, rank=0, world=1):
     raise SystemExit(f"unknown --config {name}")
 
 
-def short_pass(name, dtype, dev, lib, timed=2):
+def short_pass(name, dtype, dev, lib, timed=2, lanes=1):
     """One BASELINE.json configuration at its per-GPU size: 1 warm-up + `timed` passes of the whole path, plus the
     forward's event-timed duration and TFLOP/s (algorithmic 2*MAC of the engine's launch list)."""
     import torch
     from bndm_amd import _lib
     from bndm_amd.unet import engine_ops
     os.environ.pop("BNDM_PROFILE_DUMP", None)    # the per-op dump is the headline workload's, written before this
-    wl = make_workload(name, 0, 0, dtype, dev)
+    wl = make_workload(name, 0, 0, dtype, dev, lanes=lanes)
     B, N, model = wl["B"], wl["N"], wl["model"]
     wl["one_pass"]()
     torch.cuda.synchronize()
@@ -297,6 +297,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per pass (default: the configuration's)")
     ap.add_argument("--nb_steps", type=int, default=0, help="denoising steps per image (default: the configuration's)")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="sampling loops as this many chains of launches on separate HIP streams inside the engine "
+                         "(bndm_unet_set_lanes; bit-identical results).  Default 1 until measured")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-only", action="store_true", help="skip the timed passes; only the per-kernel profile")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -342,7 +345,7 @@ def main():
     lib = _lib.load()
 
     torch.manual_seed(1234 + rank)
-    wl = make_workload(args.config, args.batch, args.nb_steps, args.dtype, dev, rank, world)
+    wl = make_workload(args.config, args.batch, args.nb_steps, args.dtype, dev, rank, world, lanes=args.lanes)
     B, N, model = wl["B"], wl["N"], wl["model"]
     metric_name, workload_name = wl["metric"], wl["workload"]
 
@@ -452,7 +455,7 @@ def main():
         del wl, model
         torch.cuda.empty_cache()
         for oc in ("c3", "c4", "c5"):
-            others[oc] = short_pass(oc, args.dtype, dev, lib)
+            others[oc] = short_pass(oc, args.dtype, dev, lib, lanes=args.lanes)
             torch.cuda.empty_cache()
         wl = None
 
@@ -467,7 +470,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload_name, "baseline_config": args.config,
-                       "global_batch": B * args.gpus, "nb_steps": N, "parallelism": f"batch-shard x{args.gpus}"},
+                       "global_batch": B * args.gpus, "nb_steps": N, "parallelism": f"batch-shard x{args.gpus}",
+                       "lanes_per_gpu": args.lanes},
             "roofline": roof,
             "stages": stages,
             # c3 / c4 / c5 at their per-GPU batch (1 warm-up + 2 timed passes each), same library, same process

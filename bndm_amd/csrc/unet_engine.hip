@@ -156,6 +156,14 @@ struct bndm_unet {
     int s_y = -1, s_h1 = -1, s_y2 = -1, s_part = -1, s_ss = -1, s_qkv = -1, s_att = -1, s_splitk = -1;
     int s_actemb = -1, s_tp = -1, s_d = -1, s_t = -1;
 
+    // Lanes (bndm_unet_set_lanes, default 1): the sampling loops cut the batch into `nlanes` chains of launches that share the
+    // weights but own a copy of every activation / scratch slot, and enqueue them on separate streams -- the samples of a
+    // batch are independent, so one chain's kernel boundaries, prologues and epilogues are another chain's K-loop time.
+    // `lane` selects the copy P() resolves to while a chain's launches are being enqueued (host side, sequential).
+    int nlanes = 1, lane = 0;
+    std::vector<hipStream_t> lane_st;    // streams of lanes 1.. (lane 0 runs on the caller's stream)
+    std::vector<hipEvent_t> lane_ev;     // [0] fork (caller's stream), [1..] join (lane streams)
+
     int dtype() const { return cfg.dtype; }
     int new_slot(size_t bytes) {
         bufs.push_back(Buf{bytes, nullptr});
@@ -164,7 +172,8 @@ struct bndm_unet {
     void grow(int slot, size_t bytes) {
         if (bufs[slot].bytes < bytes) bufs[slot].bytes = bytes;
     }
-    void *P(int slot) const { return bufs[slot].ptr; }
+    static size_t lane_stride(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+    void *P(int slot) const { return lane ? (char *)bufs[slot].ptr + (size_t)lane * lane_stride(bufs[slot].bytes) : bufs[slot].ptr; }
     const std::vector<float> &hp(const std::string &n) const { return host[pindex.at(n)]; }
 };
 
@@ -872,7 +881,7 @@ struct Builder {
         void *dDesc = nullptr, *dRounds = nullptr;
         if ((rc = upload_16(h, plan.wgt, &dW))) return srcs[0].a;
         if ((rc = upload(h, plan.desc.data(), plan.desc.size() * 4, &dDesc))) return srcs[0].a;
-        std::vector<TailRound> rt(plan.nrounds);
+        std::vector<TailRound> rt((size_t)plan.nrounds * h->nlanes);         // one table per lane (source pointers)
         if ((rc = upload(h, rt.data(), rt.size() * sizeof(TailRound), &dRounds))) return srcs[0].a;
         {
             std::vector<int> slots;
@@ -880,17 +889,23 @@ struct Builder {
             const std::vector<TailPlanRound> pr = plan.rounds;
             std::vector<int> cs;
             for (const TSrc &t : srcs) cs.push_back(t.a.C);
+            const size_t nr = (size_t)plan.nrounds;                    // (= pr.size(); the launch indexes lanes by nrounds)
             post_alloc.push_back([=]() {
-                std::vector<TailRound> tab(pr.size());
-                for (size_t i = 0; i < pr.size(); ++i) {
-                    tab[i].src = hh->P(slots[pr[i].seg]);
-                    tab[i].row_bytes = cs[pr[i].seg] * 2;
-                    tab[i].cbyte = pr[i].c0 * 2;
-                    tab[i].mode = pr[i].mode;
-                    tab[i].phase = pr[i].phase;
-                    tab[i].nsub = pr[i].nsub;
-                    tab[i].pad = 0;
+                std::vector<TailRound> tab(nr * hh->nlanes);
+                for (int ln = 0; ln < hh->nlanes; ++ln) {
+                    hh->lane = ln;
+                    for (size_t i = 0; i < pr.size() && i < nr; ++i) {
+                        TailRound &t = tab[ln * nr + i];
+                        t.src = hh->P(slots[pr[i].seg]);
+                        t.row_bytes = cs[pr[i].seg] * 2;
+                        t.cbyte = pr[i].c0 * 2;
+                        t.mode = pr[i].mode;
+                        t.phase = pr[i].phase;
+                        t.nsub = pr[i].nsub;
+                        t.pad = 0;
+                    }
                 }
+                hh->lane = 0;
                 BNDM_CHECK_HIP(hipMemcpy(dRounds, tab.data(), tab.size() * sizeof(TailRound), hipMemcpyHostToDevice));
                 return 0;
             });
@@ -930,6 +945,7 @@ struct Builder {
         push(OPC_CONV, 2.0 * mac * rows * HW + (qkv ? 4.0 * HW * HW * Cout : 0.0), [=](RunCtx &r) {
             TailArgs c = a;
             c.B = r.B;
+            c.rounds = a.rounds + (size_t)hh->lane * a.nrounds;
             for (size_t i = 0; i < prs.size(); ++i) {
                 TailRound &d = i ? c.r1 : c.r0;
                 d = TailRound{hh->P(rslots[prs[i].seg]), rcs[prs[i].seg] * 2, prs[i].c0 * 2, prs[i].mode, prs[i].phase,
@@ -1585,6 +1601,32 @@ int check_ready(const bndm_unet *h, int B, const char *what) {
     return 0;
 }
 
+// Fork / join of the sampling loops' chains (bndm_unet::nlanes): lane 0 stays on the caller's stream, lanes 1.. run on the
+// handle's own streams, which wait for everything the caller's stream holds at the fork and are waited for at the join --
+// to the caller the loop is still one in-order piece of work on `st`.
+struct LaneFork {
+    bndm_unet *h = nullptr;
+    hipStream_t st = nullptr;
+    int n = 1;
+    int open(bndm_unet *hh, int B, hipStream_t s) {
+        h = hh;
+        st = s;
+        n = (!hh->f32 && hh->nlanes > 1 && B % hh->nlanes == 0) ? hh->nlanes : 1;
+        if (n == 1) return 0;
+        BNDM_CHECK_HIP(hipEventRecord(h->lane_ev[0], st));
+        for (int k = 1; k < n; ++k) BNDM_CHECK_HIP(hipStreamWaitEvent(h->lane_st[k - 1], h->lane_ev[0], 0));
+        return 0;
+    }
+    hipStream_t stream(int k) const { return k ? h->lane_st[k - 1] : st; }
+    int close() {
+        for (int k = 1; k < n; ++k) {
+            BNDM_CHECK_HIP(hipEventRecord(h->lane_ev[k], h->lane_st[k - 1]));
+            BNDM_CHECK_HIP(hipStreamWaitEvent(st, h->lane_ev[k], 0));
+        }
+        return 0;
+    }
+};
+
 }  // namespace
 
 // ================================================================================================
@@ -1691,6 +1733,13 @@ extern "C" void bndm_unet_destroy(bndm_unet *h) {
     if (h->t_pinned) (void)hipHostFree(h->t_pinned);
     if (h->t_uploaded) (void)hipEventDestroy(h->t_uploaded);
     for (void *p : h->retired) (void)hipFree(p);
+    for (hipStream_t s : h->lane_st)
+        if (s) {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamDestroy(s);
+        }
+    for (hipEvent_t e : h->lane_ev)
+        if (e) (void)hipEventDestroy(e);
     if (h->f32) f32_model_destroy(h->f32);
     for (Buf &b : h->bufs)
         if (b.ptr) (void)hipFree(b.ptr);
@@ -1719,6 +1768,18 @@ extern "C" int bndm_unet_load_param(bndm_unet *h, const char *name, const float 
                  (long long)ps.numel, (long long)numel);
     h->host[it->second].assign(host_data, host_data + numel);
     h->loaded[it->second] = 1;
+    return 0;
+}
+
+extern "C" int bndm_unet_set_lanes(bndm_unet *h, int lanes) {
+    BNDM_REQUIRE(h, "bndm_unet_set_lanes: NULL handle");
+    BNDM_REQUIRE(lanes >= 1 && lanes <= 4, "bndm_unet_set_lanes: %d lanes (1..4)", lanes);
+    BNDM_REQUIRE(h->kind == 0 && h->cfg.dtype != BNDM_DTYPE_F32, "bndm_unet_set_lanes: UNet handles in f16 / bf16 only");
+    if (h->finalized) {
+        set_error("bndm_unet_set_lanes: handle already finalised (the buffer copies are laid out by bndm_unet_finalize)");
+        return BNDM_E_STATE;
+    }
+    h->nlanes = lanes;
     return 0;
 }
 
@@ -1771,7 +1832,14 @@ extern "C" int bndm_unet_finalize(bndm_unet *h) {
             for (Op &o : h->ops) o.dominant = o.kernel == "conv_t32<TH=8>";
     }
     for (Buf &bf : h->bufs) {
-        BNDM_CHECK_HIP(hipMalloc(&bf.ptr, bf.bytes ? bf.bytes : 16));
+        const size_t nb = h->nlanes > 1 ? bndm_unet::lane_stride(bf.bytes) * h->nlanes : bf.bytes;
+        BNDM_CHECK_HIP(hipMalloc(&bf.ptr, nb ? nb : 16));
+    }
+    if (h->nlanes > 1) {
+        h->lane_st.assign(h->nlanes - 1, nullptr);
+        h->lane_ev.assign(h->nlanes, nullptr);
+        for (hipStream_t &s : h->lane_st) BNDM_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        for (hipEvent_t &e : h->lane_ev) BNDM_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     for (auto &fn : b.post_alloc)
         if ((rc = fn())) return rc;
@@ -1803,22 +1871,40 @@ extern "C" int bndm_unet_sample_iadb(bndm_unet *h, float *x, const float *extra_
                  extra_in ? " (with conditioning)" : "");
     BNDM_REQUIRE(Cout == C || Cout == 2 * C, "bndm_unet_sample_iadb: out_channel %d for %d image channels", Cout, C);
     hipStream_t st = (hipStream_t)stream;
-    float *tbuf = (float *)h->P(h->s_t), *dbuf = (float *)h->P(h->s_d);
     const size_t img = (size_t)B * C * R * R;
     int snap = 0;
     if (nb_step > 0 && !h->f32 && (rc = prepare_temb_table(h, nb_step, t_in, st))) return rc;
-    for (int s = 0; s < nb_step; ++s) {
-        RunCtx r{B, st, x, extra_in, tbuf, dbuf};
-        if (h->f32) hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(64), 0, st, tbuf, t_in[s], B);
-        else r.tp_row = h->tp_table + (size_t)s * h->ntemb;
-        if ((rc = run_forward(h, r))) return rc;
-        if ((rc = bndm_iadb_step(x, dbuf, da[s], dg[s], B, C, Cout, R * R, stream))) return rc;
-        if (snap_mask && snapshots && snap_mask[s]) {
-            BNDM_CHECK_HIP(hipMemcpyAsync(snapshots + (size_t)snap * img, x, img * 4, hipMemcpyDeviceToDevice, st));
-            ++snap;
+    // chains: lane k owns samples [k * Bl, (k + 1) * Bl) and the k-th copy of every buffer slot; one chain (the whole batch on
+    // the caller's stream) unless bndm_unet_set_lanes asked for more and the batch divides
+    LaneFork lf;
+    if ((rc = lf.open(h, B, st))) return rc;
+    const int Bl = B / lf.n;
+    const size_t per = (size_t)C * R * R;                   // floats per sample of x (and of extra_in: Cin - C = C channels)
+    for (int s = 0; s < nb_step && !rc; ++s) {
+        for (int k = 0; k < lf.n && !rc; ++k) {
+            h->lane = k;
+            hipStream_t sk = lf.stream(k);
+            float *xk = x + (size_t)k * Bl * per;
+            float *tbuf = (float *)h->P(h->s_t), *dbuf = (float *)h->P(h->s_d);
+            RunCtx r{Bl, sk, xk, extra_in ? extra_in + (size_t)k * Bl * per : nullptr, tbuf, dbuf};
+            if (h->f32) hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(64), 0, sk, tbuf, t_in[s], Bl);
+            else r.tp_row = h->tp_table + (size_t)s * h->ntemb;
+            if ((rc = run_forward(h, r))) break;
+            if ((rc = bndm_iadb_step(xk, dbuf, da[s], dg[s], Bl, C, Cout, R * R, sk))) break;
+            if (snap_mask && snapshots && snap_mask[s]) {
+                const hipError_t e = hipMemcpyAsync(snapshots + (size_t)snap * img + (size_t)k * Bl * per, xk, (size_t)Bl * per * 4,
+                                                    hipMemcpyDeviceToDevice, sk);
+                if (e != hipSuccess) {
+                    set_error("bndm_unet_sample_iadb: snapshot copy: %s", hipGetErrorString(e));
+                    rc = BNDM_E_ARG;
+                }
+            }
         }
+        if (snap_mask && snapshots && snap_mask[s]) ++snap;
     }
-    return 0;
+    h->lane = 0;
+    const int rj = lf.close();                              // the caller's stream waits for every chain, also after an error
+    return rc ? rc : rj;
 }
 
 extern "C" int bndm_unet_sample_ddim(bndm_unet *h, float *x, int B, int nb_step, const float *coef, float clip,
@@ -1829,22 +1915,32 @@ extern "C" int bndm_unet_sample_ddim(bndm_unet *h, float *x, int B, int nb_step,
     BNDM_REQUIRE(h->cfg.in_channels == h->cfg.out_channels, "bndm_unet_sample_ddim: eps-prediction needs Cin == Cout");
     hipStream_t st = (hipStream_t)stream;
     const int R = h->cfg.resolution;
-    float *tbuf = (float *)h->P(h->s_t), *dbuf = (float *)h->P(h->s_d);
-    const size_t n = (size_t)B * h->cfg.in_channels * R * R;
     if (nb_step > 0) {
         std::vector<float> ts(nb_step);
         for (int s = 0; s < nb_step; ++s) ts[s] = coef[5 * s];
         if (!h->f32 && (rc = prepare_temb_table(h, nb_step, ts.data(), st))) return rc;   // copied to pinned staging there
     }
-    for (int s = 0; s < nb_step; ++s) {
+    LaneFork lf;                                             // chains as in bndm_unet_sample_iadb
+    if ((rc = lf.open(h, B, st))) return rc;
+    const int Bl = B / lf.n;
+    const size_t per = (size_t)h->cfg.in_channels * R * R;
+    for (int s = 0; s < nb_step && !rc; ++s) {
         const float *c = coef + 5 * s;
-        RunCtx r{B, st, x, nullptr, tbuf, dbuf};
-        if (h->f32) hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(64), 0, st, tbuf, c[0], B);
-        else r.tp_row = h->tp_table + (size_t)s * h->ntemb;
-        if ((rc = run_forward(h, r))) return rc;
-        if ((rc = bndm_ddim_step(x, dbuf, c[1], c[2], c[3], c[4], clip, n, stream))) return rc;
+        for (int k = 0; k < lf.n && !rc; ++k) {
+            h->lane = k;
+            hipStream_t sk = lf.stream(k);
+            float *xk = x + (size_t)k * Bl * per;
+            float *tbuf = (float *)h->P(h->s_t), *dbuf = (float *)h->P(h->s_d);
+            RunCtx r{Bl, sk, xk, nullptr, tbuf, dbuf};
+            if (h->f32) hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(64), 0, sk, tbuf, c[0], Bl);
+            else r.tp_row = h->tp_table + (size_t)s * h->ntemb;
+            if ((rc = run_forward(h, r))) break;
+            rc = bndm_ddim_step(xk, dbuf, c[1], c[2], c[3], c[4], clip, (size_t)Bl * per, sk);
+        }
     }
-    return 0;
+    h->lane = 0;
+    const int rj = lf.close();
+    return rc ? rc : rj;
 }
 
 extern "C" int bndm_unet_profile(bndm_unet *h, const float *sample, const float *timesteps, float *out, int B,

@@ -12,6 +12,10 @@ tools/ubench/t32_bench.bin 16 1 0
 mkdir -p /tmp/cand && cp tools/lib_v8.so /tmp/cand/libbndm_hip.so
 LD_LIBRARY_PATH=/tmp/cand tools/ubench/t32_bench.bin 16 1 0
 LD_LIBRARY_PATH=/tmp/cand tools/ubench/t32_bench.bin 32 1 0
+echo "== 3a. lanes: the loop as two / four chains on separate streams (host-thread form and in-engine form), then the parked tests"
+python tools/two_stream.py --passes 2 --nb_steps 100 2>&1 | tail -5
+python tools/two_stream.py --passes 2 --nb_steps 100 --lanes 4 2>&1 | tail -5
+python -m pytest tools/experiments/extra_tests/test_gpu_lanes.py -m gpu -q 2>&1 | tail -5
 echo "== 3b. never-run extra tests (first-level widths 64 / 256):  python -m pytest tools/experiments/extra_tests -m gpu -q -s"
 echo "== 4. if a candidate wins: apply its patch, rebuild, then the full suite:  python -m pytest tests -m gpu -x -q"
 echo "== 5. capture: bash tools/profile_round.sh r05   (copies to profiles/ by hand)"

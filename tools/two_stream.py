@@ -1,0 +1,122 @@
+"""Experiment (not product): the c2 denoising loop as TWO half-batch chains on two HIP streams.
+
+Why: a conv_t32 launch is 2 rounds x (prologue + K loop + epilogue) and the two workgroups of a CU are phase-locked (both in
+the prologue, then both in the epilogue: DESIGN section 8), so the MFMA pipe idles for a third of every launch, and every
+kernel boundary (94 per forward) drains the chip.  The samples of a batch are independent (GroupNorm and attention are per
+sample; tests/test_gpu_benched.py::test_batch_position_independence), so the batch can be cut into two chains of launches
+that depend on nothing of each other.  On two streams the dispatcher fills a CU slot freed by chain A's finishing workgroup
+with chain B's next kernel: A's epilogue / drain / launch gap is B's K-loop time, without any change to a kernel.
+
+    python tools/two_stream.py [--batch 64] [--nb_steps 250] [--passes 3] [--lanes 2] [lib.so]
+
+Three forms, alternating on one box: the one-stream loop, the chains driven by one host thread each with an engine handle each
+(no change to the library at all), and the product form -- bndm_unet_set_lanes: one handle, one host thread, chains enqueued
+step by step.
+
+Prints images/s of the one-stream loop (= bench.py's timed region without noise / export) and of the two-stream form on the
+same box, alternating, and checks that the results are bit-identical (they must be: same kernels per sample, and the kernel
+choice by grid size is the only thing that can differ -- reported if it does)."""
+import argparse
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("lib", nargs="?", default=None)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--nb_steps", type=int, default=250)
+    ap.add_argument("--passes", type=int, default=3)
+    ap.add_argument("--lanes", type=int, default=2)
+    ap.add_argument("--res", type=int, default=64)
+    ap.add_argument("--handle-batch", default="full", choices=["full", "lane"],
+                    help="max_batch of a chain's engine handle: tile sizes are chosen from it at build time.  'full' keeps the "
+                         "B-sample choices (bit-identical results expected), 'lane' lets the engine choose for B / lanes")
+    a = ap.parse_args()
+    from bndm_amd import _lib
+    if a.lib:
+        _lib.LIB_PATH = os.path.abspath(a.lib)
+    import torch
+    from bndm_amd.sampler import get_model, sample_iadb
+    from bndm_amd.unet import engine_ops
+
+    dev = torch.device("cuda:0")
+    B, N, R, NL = a.batch, a.nb_steps, a.res, a.lanes
+    assert B % NL == 0
+    params = torch.tensor([1000.0, 0.0, 3.0], device=dev)
+    full = get_model(3, 6, R, dtype="f16", seed=0).to(dev).eval()
+    lanes = [get_model(3, 6, R, dtype="f16", seed=0).to(dev).eval() for _ in range(NL)]      # same seed = same weights
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NL)]
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(B, 3, R, R, generator=g).to(dev)
+    hb = B // NL
+    if a.handle_batch == "full":
+        for m in lanes:
+            m._ensure_engine(B, R, dev)          # the handle is kept for any smaller batch
+
+    def one_stream():
+        return sample_iadb(full, x0, N, "sigmoid", params, 6, "gaussianBN", "train")
+
+    def multi_stream():
+        out = [None] * NL
+        cur = torch.cuda.current_stream(dev)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+
+        def work(i):
+            # one host thread per chain: a sampling call enqueues its whole loop (steps x 95 launches) before it returns,
+            # and ctypes drops the GIL inside it
+            with torch.cuda.device(dev), torch.cuda.stream(streams[i]):
+                streams[i].wait_event(ev)
+                out[i] = sample_iadb(lanes[i], x0[i * hb:(i + 1) * hb], N, "sigmoid", params, 6, "gaussianBN", "train")
+        th = [threading.Thread(target=work, args=(i,)) for i in range(NL)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for s in streams:
+            cur.wait_stream(s)
+        return torch.cat(out, 0)
+
+    eng = get_model(3, 6, R, dtype="f16", seed=0, lanes=NL).to(dev).eval()      # the product form: chains inside the engine
+
+    def in_engine():
+        return sample_iadb(eng, x0, N, "sigmoid", params, 6, "gaussianBN", "train")
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        y = fn()
+        torch.cuda.synchronize()
+        return y, time.perf_counter() - t0
+
+    ya, _ = timed(one_stream)
+    yb, _ = timed(multi_stream)
+    same = bool(torch.equal(ya, yb))
+    if not same:
+        d = (ya - yb).abs().max().item()
+        print(f"results differ: max abs {d:.3e} (kernel choice by grid size differs between B={B} and B={hb}?)")
+        ka = [k for k, _, _ in engine_ops(full._ensure_engine(B, R, dev))]
+        kb = [k for k, _, _ in engine_ops(lanes[0]._ensure_engine(hb, R, dev))]
+        print("   launch lists differ at ops:", [i for i, (p, q) in enumerate(zip(ka, kb)) if p != q][:20])
+    yc, _ = timed(in_engine)
+    same_c = bool(torch.equal(ya, yc))
+    ta, tb, tc = [], [], []
+    for _ in range(a.passes):
+        ta.append(timed(one_stream)[1])
+        tb.append(timed(multi_stream)[1])
+        tc.append(timed(in_engine)[1])
+    fa, fb, fc = B / min(ta), B / min(tb), B / min(tc)
+    print(f"one stream  B={B}: {fa:8.2f} images/s   ({min(ta) / N * 1e3:.3f} ms per step)   all: {[round(B / t, 1) for t in ta]}")
+    print(f"{NL} streams B={hb}x{NL}: {fb:8.2f} images/s   ({min(tb) / N * 1e3:.3f} ms per step)   all: {[round(B / t, 1) for t in tb]}")
+    print(f"in-engine lanes={NL}: {fc:8.2f} images/s   ({min(tc) / N * 1e3:.3f} ms per step)   all: {[round(B / t, 1) for t in tc]}")
+    print(f"ratio host threads {fb / fa:.3f} (bit-identical: {same})   in-engine {fc / fa:.3f} (bit-identical: {same_c})")
+
+
+if __name__ == "__main__":
+    main()
