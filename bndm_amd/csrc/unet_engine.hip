@@ -18,6 +18,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -127,6 +128,9 @@ struct Op {
 
 }  // namespace
 
+// lane whose launches the calling thread is enqueueing (bndm_unet::P resolves buffer slots to that lane's copies)
+static thread_local int t_lane = 0;
+
 struct bndm_unet {
     bndm_unet_config cfg{};
     int kind = 0;                      // 0: UNet2DModel, 1: AutoencoderKL decoder (cfg.resolution = latent H = W)
@@ -159,8 +163,10 @@ struct bndm_unet {
     // Lanes (bndm_unet_set_lanes, default 1): the sampling loops cut the batch into `nlanes` chains of launches that share the
     // weights but own a copy of every activation / scratch slot, and enqueue them on separate streams -- the samples of a
     // batch are independent, so one chain's kernel boundaries, prologues and epilogues are another chain's K-loop time.
-    // `lane` selects the copy P() resolves to while a chain's launches are being enqueued (host side, sequential).
-    int nlanes = 1, lane = 0;
+    // The thread-local `t_lane` selects the copy P() resolves to while a thread enqueues a chain's launches; the chains are
+    // enqueued step by step by the calling thread, or (lane_threads) by one host thread per chain.
+    int nlanes = 1;
+    bool lane_threads = false;
     std::vector<hipStream_t> lane_st;    // streams of lanes 1.. (lane 0 runs on the caller's stream)
     std::vector<hipEvent_t> lane_ev;     // [0] fork (caller's stream), [1..] join (lane streams)
 
@@ -173,7 +179,7 @@ struct bndm_unet {
         if (bufs[slot].bytes < bytes) bufs[slot].bytes = bytes;
     }
     static size_t lane_stride(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
-    void *P(int slot) const { return lane ? (char *)bufs[slot].ptr + (size_t)lane * lane_stride(bufs[slot].bytes) : bufs[slot].ptr; }
+    void *P(int slot) const { return t_lane ? (char *)bufs[slot].ptr + (size_t)t_lane * lane_stride(bufs[slot].bytes) : bufs[slot].ptr; }
     const std::vector<float> &hp(const std::string &n) const { return host[pindex.at(n)]; }
 };
 
@@ -893,7 +899,7 @@ struct Builder {
             post_alloc.push_back([=]() {
                 std::vector<TailRound> tab(nr * hh->nlanes);
                 for (int ln = 0; ln < hh->nlanes; ++ln) {
-                    hh->lane = ln;
+                    t_lane = ln;
                     for (size_t i = 0; i < pr.size() && i < nr; ++i) {
                         TailRound &t = tab[ln * nr + i];
                         t.src = hh->P(slots[pr[i].seg]);
@@ -905,7 +911,7 @@ struct Builder {
                         t.pad = 0;
                     }
                 }
-                hh->lane = 0;
+                t_lane = 0;
                 BNDM_CHECK_HIP(hipMemcpy(dRounds, tab.data(), tab.size() * sizeof(TailRound), hipMemcpyHostToDevice));
                 return 0;
             });
@@ -945,7 +951,7 @@ struct Builder {
         push(OPC_CONV, 2.0 * mac * rows * HW + (qkv ? 4.0 * HW * HW * Cout : 0.0), [=](RunCtx &r) {
             TailArgs c = a;
             c.B = r.B;
-            c.rounds = a.rounds + (size_t)hh->lane * a.nrounds;
+            c.rounds = a.rounds + (size_t)t_lane * a.nrounds;
             for (size_t i = 0; i < prs.size(); ++i) {
                 TailRound &d = i ? c.r1 : c.r0;
                 d = TailRound{hh->P(rslots[prs[i].seg]), rcs[prs[i].seg] * 2, prs[i].c0 * 2, prs[i].mode, prs[i].phase,
@@ -1618,6 +1624,45 @@ struct LaneFork {
         return 0;
     }
     hipStream_t stream(int k) const { return k ? h->lane_st[k - 1] : st; }
+    // step(k, s): enqueue step s of chain k on stream(k).  One thread walks the steps and deals every step to the chains
+    // in turn, or (lane_threads) every chain gets a host thread of its own that walks all steps.
+    int run(int nsteps, const std::function<int(int, int)> &step) {
+        int rc = 0;
+        if (n == 1 || !h->lane_threads) {
+            for (int s = 0; s < nsteps && !rc; ++s)
+                for (int k = 0; k < n && !rc; ++k) {
+                    t_lane = k;
+                    rc = step(k, s);
+                }
+            t_lane = 0;
+            return rc;
+        }
+        int dev = 0;
+        BNDM_CHECK_HIP(hipGetDevice(&dev));
+        std::vector<int> rcs(n, 0);
+        std::vector<std::string> msgs(n);
+        auto chain = [&](int k) {
+            t_lane = k;
+            if (k && hipSetDevice(dev) != hipSuccess) {                 // (the current device is per thread)
+                rcs[k] = BNDM_E_NODEVICE;
+                msgs[k] = "lane thread: hipSetDevice failed";
+                return;
+            }
+            for (int s = 0; s < nsteps && !rcs[k]; ++s) rcs[k] = step(k, s);
+            if (rcs[k]) msgs[k] = bndm_last_error();                    // the error text is per thread
+            t_lane = 0;
+        };
+        std::vector<std::thread> th;
+        for (int k = 1; k < n; ++k) th.emplace_back(chain, k);
+        chain(0);
+        for (std::thread &t : th) t.join();
+        for (int k = 0; k < n; ++k)
+            if (rcs[k]) {
+                set_error("%s", msgs[k].c_str());
+                return rcs[k];
+            }
+        return 0;
+    }
     int close() {
         for (int k = 1; k < n; ++k) {
             BNDM_CHECK_HIP(hipEventRecord(h->lane_ev[k], h->lane_st[k - 1]));
@@ -1771,7 +1816,7 @@ extern "C" int bndm_unet_load_param(bndm_unet *h, const char *name, const float 
     return 0;
 }
 
-extern "C" int bndm_unet_set_lanes(bndm_unet *h, int lanes) {
+extern "C" int bndm_unet_set_lanes(bndm_unet *h, int lanes, int host_threads) {
     BNDM_REQUIRE(h, "bndm_unet_set_lanes: NULL handle");
     BNDM_REQUIRE(lanes >= 1 && lanes <= 4, "bndm_unet_set_lanes: %d lanes (1..4)", lanes);
     BNDM_REQUIRE(h->kind == 0 && h->cfg.dtype != BNDM_DTYPE_F32, "bndm_unet_set_lanes: UNet handles in f16 / bf16 only");
@@ -1780,6 +1825,7 @@ extern "C" int bndm_unet_set_lanes(bndm_unet *h, int lanes) {
         return BNDM_E_STATE;
     }
     h->nlanes = lanes;
+    h->lane_threads = host_threads != 0 && lanes > 1;
     return 0;
 }
 
@@ -1872,7 +1918,6 @@ extern "C" int bndm_unet_sample_iadb(bndm_unet *h, float *x, const float *extra_
     BNDM_REQUIRE(Cout == C || Cout == 2 * C, "bndm_unet_sample_iadb: out_channel %d for %d image channels", Cout, C);
     hipStream_t st = (hipStream_t)stream;
     const size_t img = (size_t)B * C * R * R;
-    int snap = 0;
     if (nb_step > 0 && !h->f32 && (rc = prepare_temb_table(h, nb_step, t_in, st))) return rc;
     // chains: lane k owns samples [k * Bl, (k + 1) * Bl) and the k-th copy of every buffer slot; one chain (the whole batch on
     // the caller's stream) unless bndm_unet_set_lanes asked for more and the batch divides
@@ -1880,29 +1925,25 @@ extern "C" int bndm_unet_sample_iadb(bndm_unet *h, float *x, const float *extra_
     if ((rc = lf.open(h, B, st))) return rc;
     const int Bl = B / lf.n;
     const size_t per = (size_t)C * R * R;                   // floats per sample of x (and of extra_in: Cin - C = C channels)
-    for (int s = 0; s < nb_step && !rc; ++s) {
-        for (int k = 0; k < lf.n && !rc; ++k) {
-            h->lane = k;
-            hipStream_t sk = lf.stream(k);
-            float *xk = x + (size_t)k * Bl * per;
-            float *tbuf = (float *)h->P(h->s_t), *dbuf = (float *)h->P(h->s_d);
-            RunCtx r{Bl, sk, xk, extra_in ? extra_in + (size_t)k * Bl * per : nullptr, tbuf, dbuf};
-            if (h->f32) hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(64), 0, sk, tbuf, t_in[s], Bl);
-            else r.tp_row = h->tp_table + (size_t)s * h->ntemb;
-            if ((rc = run_forward(h, r))) break;
-            if ((rc = bndm_iadb_step(xk, dbuf, da[s], dg[s], Bl, C, Cout, R * R, sk))) break;
-            if (snap_mask && snapshots && snap_mask[s]) {
-                const hipError_t e = hipMemcpyAsync(snapshots + (size_t)snap * img + (size_t)k * Bl * per, xk, (size_t)Bl * per * 4,
-                                                    hipMemcpyDeviceToDevice, sk);
-                if (e != hipSuccess) {
-                    set_error("bndm_unet_sample_iadb: snapshot copy: %s", hipGetErrorString(e));
-                    rc = BNDM_E_ARG;
-                }
-            }
-        }
-        if (snap_mask && snapshots && snap_mask[s]) ++snap;
-    }
-    h->lane = 0;
+    std::vector<int> snap_at(nb_step > 0 ? nb_step : 1, -1);           // snapshot index of step s, or -1
+    if (snap_mask && snapshots)
+        for (int s = 0, n = 0; s < nb_step; ++s)
+            if (snap_mask[s]) snap_at[s] = n++;
+    rc = lf.run(nb_step, [&](int k, int s) -> int {
+        hipStream_t sk = lf.stream(k);
+        float *xk = x + (size_t)k * Bl * per;
+        float *tbuf = (float *)h->P(h->s_t), *dbuf = (float *)h->P(h->s_d);
+        RunCtx r{Bl, sk, xk, extra_in ? extra_in + (size_t)k * Bl * per : nullptr, tbuf, dbuf};
+        if (h->f32) hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(64), 0, sk, tbuf, t_in[s], Bl);
+        else r.tp_row = h->tp_table + (size_t)s * h->ntemb;
+        int e = run_forward(h, r);
+        if (e) return e;
+        if ((e = bndm_iadb_step(xk, dbuf, da[s], dg[s], Bl, C, Cout, R * R, sk))) return e;
+        if (snap_at[s] >= 0)
+            BNDM_CHECK_HIP(hipMemcpyAsync(snapshots + (size_t)snap_at[s] * img + (size_t)k * Bl * per, xk, (size_t)Bl * per * 4,
+                                          hipMemcpyDeviceToDevice, sk));
+        return 0;
+    });
     const int rj = lf.close();                              // the caller's stream waits for every chain, also after an error
     return rc ? rc : rj;
 }
@@ -1924,21 +1965,17 @@ extern "C" int bndm_unet_sample_ddim(bndm_unet *h, float *x, int B, int nb_step,
     if ((rc = lf.open(h, B, st))) return rc;
     const int Bl = B / lf.n;
     const size_t per = (size_t)h->cfg.in_channels * R * R;
-    for (int s = 0; s < nb_step && !rc; ++s) {
+    rc = lf.run(nb_step, [&](int k, int s) -> int {
         const float *c = coef + 5 * s;
-        for (int k = 0; k < lf.n && !rc; ++k) {
-            h->lane = k;
-            hipStream_t sk = lf.stream(k);
-            float *xk = x + (size_t)k * Bl * per;
-            float *tbuf = (float *)h->P(h->s_t), *dbuf = (float *)h->P(h->s_d);
-            RunCtx r{Bl, sk, xk, nullptr, tbuf, dbuf};
-            if (h->f32) hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(64), 0, sk, tbuf, c[0], Bl);
-            else r.tp_row = h->tp_table + (size_t)s * h->ntemb;
-            if ((rc = run_forward(h, r))) break;
-            rc = bndm_ddim_step(xk, dbuf, c[1], c[2], c[3], c[4], clip, (size_t)Bl * per, sk);
-        }
-    }
-    h->lane = 0;
+        hipStream_t sk = lf.stream(k);
+        float *xk = x + (size_t)k * Bl * per;
+        float *tbuf = (float *)h->P(h->s_t), *dbuf = (float *)h->P(h->s_d);
+        RunCtx r{Bl, sk, xk, nullptr, tbuf, dbuf};
+        if (h->f32) hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(64), 0, sk, tbuf, c[0], Bl);
+        else r.tp_row = h->tp_table + (size_t)s * h->ntemb;
+        const int e = run_forward(h, r);
+        return e ? e : bndm_ddim_step(xk, dbuf, c[1], c[2], c[3], c[4], clip, (size_t)Bl * per, sk);
+    });
     const int rj = lf.close();
     return rc ? rc : rj;
 }

@@ -9,15 +9,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _models(lanes, cout=6, res=64, dtype="f16"):
+def _models(lanes, cout=6, res=64, dtype="f16", threads=False):
     from bndm_amd.sampler import get_model
-    return [get_model(3, cout, res, dtype=dtype, seed=5, lanes=n).cuda().eval() for n in lanes]
+    return [get_model(3, cout, res, dtype=dtype, seed=5, lanes=n, lane_threads=threads).cuda().eval() for n in lanes]
 
 
-@pytest.mark.parametrize("B,lanes", [(8, 2), (8, 4), (6, 2)])
-def test_iadb_loop_lanes_bit_identical(B, lanes):
+@pytest.mark.parametrize("B,lanes,threads", [(8, 2, False), (8, 4, False), (6, 2, False), (8, 2, True), (8, 4, True)])
+def test_iadb_loop_lanes_bit_identical(B, lanes, threads):
     from bndm_amd.sampler import sample_iadb
-    m1, mn = _models((1, lanes))
+    m1, mn = _models((1, lanes), threads=threads)
     x0 = torch.randn(B, 3, 64, 64, generator=torch.Generator().manual_seed(B)).cuda()
     p = torch.tensor([1000.0, 0.0, 3.0], device="cuda")
     a, xa, _ = sample_iadb(m1, x0, 6, "sigmoid", p, 6, "gaussianBN", "test", log_freq=2)
@@ -79,7 +79,7 @@ def test_set_lanes_contract():
     lib = _lib.load()
     m = _models((2,))[0]
     h = m._ensure_engine(2, 64, torch.device("cuda", 0))
-    assert lib.bndm_unet_set_lanes(h, 2) == -2                      # BNDM_E_STATE: already finalised
+    assert lib.bndm_unet_set_lanes(h, 2, 0) == -2                      # BNDM_E_STATE: already finalised
     assert b"finalised" in lib.bndm_last_error()
     with pytest.raises(_lib.BndmError):
         _models((5,))[0]._ensure_engine(2, 64, torch.device("cuda", 0))

@@ -2,20 +2,29 @@
 # What to run first when a GPU is available again (round 4 ended with GPU access closed; see profiles/r04_README.md).
 # Candidate libraries are built from the patches under tools/experiments/ (tools/build_candidates.sh); everything is A/B'd on one
 # box against the shipped library before anything is applied to the product sources.
+#   on the build box first:   make -C bndm_amd/csrc && bash tools/build_candidates.sh && bash tools/ubench/build.sh
 #   usage (on the GPU box, from the repo root):  bash tools/next_gpu_session.sh 2>&1 | tee gpurun_out/next_session.log
 R=$(cd "$(dirname "$0")/.." && pwd); cd $R; mkdir -p gpurun_out
 echo "== 1. smoke of the shipped library"; python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-echo "== 2. A/B: shipped vs candidates (per-op profile, accuracy vs the fp32 mode)"
+echo "== 2. lanes (bndm_unet_set_lanes): parked tests, then one stream vs host-thread chains vs in-engine chains, 2 and 4 lanes"
+python -m pytest tools/experiments/extra_tests/test_gpu_lanes.py -m gpu -q -x 2>&1 | tail -5
+python tools/two_stream.py --passes 2 --nb_steps 100 2>&1 | tail -5
+python tools/two_stream.py --passes 2 --nb_steps 100 --lanes 4 2>&1 | tail -5
+for n in 1 2 4; do
+  echo "-- bench.py --lanes $n"
+  python bench.py --lanes $n --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); o=d.get('other_configs') or {}
+print('   c2', d['value'], 'images/s;', {k:(v['value'], v['ms_per_forward']) for k,v in o.items()})"
+done
+echo "== 3. A/B: shipped vs candidates (per-op profile, accuracy vs the fp32 mode)"
 python tools/ab_libs.py --rounds 2 --acc bndm_amd/libbndm_hip.so tools/lib_v6.so tools/lib_v7.so "tools/lib_v8.so@BNDM_TH32_MIN=256" 2>&1 | tail -14
-echo "== 3. grid sweep of single conv_t32 launches: shipped TH=16, candidate TH=16 and TH=32"
+echo "== 4. grid sweep of single conv_t32 launches: shipped TH=16, candidate TH=16 and TH=32"
 tools/ubench/t32_bench.bin 16 1 0
 mkdir -p /tmp/cand && cp tools/lib_v8.so /tmp/cand/libbndm_hip.so
 LD_LIBRARY_PATH=/tmp/cand tools/ubench/t32_bench.bin 16 1 0
 LD_LIBRARY_PATH=/tmp/cand tools/ubench/t32_bench.bin 32 1 0
-echo "== 3a. lanes: the loop as two / four chains on separate streams (host-thread form and in-engine form), then the parked tests"
-python tools/two_stream.py --passes 2 --nb_steps 100 2>&1 | tail -5
-python tools/two_stream.py --passes 2 --nb_steps 100 --lanes 4 2>&1 | tail -5
-python -m pytest tools/experiments/extra_tests/test_gpu_lanes.py -m gpu -q 2>&1 | tail -5
-echo "== 3b. never-run extra tests (first-level widths 64 / 256):  python -m pytest tools/experiments/extra_tests -m gpu -q -s"
-echo "== 4. if a candidate wins: apply its patch, rebuild, then the full suite:  python -m pytest tests -m gpu -x -q"
-echo "== 5. capture: bash tools/profile_round.sh r05   (copies to profiles/ by hand)"
+echo "== 4b. never-run extra tests (first-level widths 64 / 256)"
+python -m pytest tools/experiments/extra_tests/test_gpu_first_level_widths.py -m gpu -q 2>&1 | tail -5
+echo "== 5. if a candidate wins: apply its patch, rebuild, then the full suite:  python -m pytest tests -m gpu -x -q"
+echo "== 6. capture: bash tools/profile_round.sh r04   (copies to profiles/ by hand)"

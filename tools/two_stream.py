@@ -84,9 +84,13 @@ def main():
         return torch.cat(out, 0)
 
     eng = get_model(3, 6, R, dtype="f16", seed=0, lanes=NL).to(dev).eval()      # the product form: chains inside the engine
+    engt = get_model(3, 6, R, dtype="f16", seed=0, lanes=NL, lane_threads=True).to(dev).eval()   # ... one host thread per chain
 
     def in_engine():
         return sample_iadb(eng, x0, N, "sigmoid", params, 6, "gaussianBN", "train")
+
+    def in_engine_threads():
+        return sample_iadb(engt, x0, N, "sigmoid", params, 6, "gaussianBN", "train")
 
     def timed(fn):
         torch.cuda.synchronize()
@@ -106,16 +110,21 @@ def main():
         print("   launch lists differ at ops:", [i for i, (p, q) in enumerate(zip(ka, kb)) if p != q][:20])
     yc, _ = timed(in_engine)
     same_c = bool(torch.equal(ya, yc))
-    ta, tb, tc = [], [], []
+    yd, _ = timed(in_engine_threads)
+    same_d = bool(torch.equal(ya, yd))
+    ta, tb, tc, td = [], [], [], []
     for _ in range(a.passes):
         ta.append(timed(one_stream)[1])
         tb.append(timed(multi_stream)[1])
         tc.append(timed(in_engine)[1])
-    fa, fb, fc = B / min(ta), B / min(tb), B / min(tc)
+        td.append(timed(in_engine_threads)[1])
+    fa, fb, fc, fd = B / min(ta), B / min(tb), B / min(tc), B / min(td)
     print(f"one stream  B={B}: {fa:8.2f} images/s   ({min(ta) / N * 1e3:.3f} ms per step)   all: {[round(B / t, 1) for t in ta]}")
     print(f"{NL} streams B={hb}x{NL}: {fb:8.2f} images/s   ({min(tb) / N * 1e3:.3f} ms per step)   all: {[round(B / t, 1) for t in tb]}")
     print(f"in-engine lanes={NL}: {fc:8.2f} images/s   ({min(tc) / N * 1e3:.3f} ms per step)   all: {[round(B / t, 1) for t in tc]}")
-    print(f"ratio host threads {fb / fa:.3f} (bit-identical: {same})   in-engine {fc / fa:.3f} (bit-identical: {same_c})")
+    print(f"in-engine lanes={NL}, a host thread per chain: {fd:8.2f} images/s   all: {[round(B / t, 1) for t in td]}")
+    print(f"ratio: engine handle + python thread per chain {fb / fa:.3f} (bit-identical: {same})   in-engine {fc / fa:.3f} "
+          f"(bit-identical: {same_c})   in-engine + threads {fd / fa:.3f} (bit-identical: {same_d})")
 
 
 if __name__ == "__main__":
