@@ -108,6 +108,7 @@ struct RunCtx {
     // time-embedding projections precomputed for the whole schedule (sampler loops): row of this step,
     // shared by every sample (batch stride 0); nullptr -> computed per forward from `timesteps`
     const float *tp_row = nullptr;
+    int chains = 1;                 // chains of launches in flight side by side (lanes): grid-size heuristics see the sum
     // profiling
     bool prof = false;
     std::vector<hipEvent_t> *ev = nullptr;
@@ -500,7 +501,7 @@ struct Builder {
             push(OPC_OTHER, 0, [=](RunCtx &r) {
                 GnSlabSrc sl;
                 if (fused_reduce) {
-                    const ConvPlan pl = plan_conv(r.B * HW, C1, q.ksteps, hh->bufs[hh->s_splitk].bytes);
+                    const ConvPlan pl = plan_conv(r.B * r.chains * HW, C1, q.ksteps, hh->bufs[hh->s_splitk].bytes);   // (as the producer planned)
                     if (pl.splitk > 1) {
                         sl.part = (const float *)hh->P(hh->s_splitk);
                         sl.splitk = pl.splitk;
@@ -641,7 +642,7 @@ struct Builder {
             c.resid = rs >= 0 ? hh->P(rs) : nullptr;
             c.out = head ? (void *)r.out : hh->P(so);
             c.stats = pst >= 0 ? (float *)hh->P(pst) : nullptr;
-            return launch_conv_t32(hh->dtype(), TH, c, r.st);
+            return launch_conv_t32(hh->dtype(), TH, c, r.st, r.chains);
         });
         h->ops[op_index].dominant = TH == 16 && !head;
         h->ops[op_index].kernel = S(head ? "conv_t32<TH=%d,N=32>" : "conv_t32<TH=%d>", TH);
@@ -670,7 +671,7 @@ struct Builder {
         cur_name = S("rdce %-44s C=%-4d %dx%d", "", q.C, q.H, q.W);
         push(OPC_OTHER, 0, [=](RunCtx &r) {
             const int M = r.B * q.H * q.W;
-            const ConvPlan pl = plan_conv(M, q.C, q.ksteps, hh->bufs[hh->s_splitk].bytes);
+            const ConvPlan pl = plan_conv(M * r.chains, q.C, q.ksteps, hh->bufs[hh->s_splitk].bytes);   // (as the producer planned)
             if (pl.splitk == 1) return 0;            // the conv wrote the tensor itself
             ConvArgs c{};
             c.B = r.B;
@@ -753,8 +754,10 @@ struct Builder {
                 c.temb = nullptr;
                 c.temb_off = 0;
             }
+            // tile / split-K are planned for the sum of the chains in flight (lanes): the choice, and with it every summation
+            // order, is that of the one-chain run of the whole batch
             const int M = r.B * c.H * c.W;
-            const ConvPlan pl = plan_conv(M, c.Cout, ksteps, hh->bufs[hh->s_splitk].bytes);
+            const ConvPlan pl = plan_conv(M * r.chains, c.Cout, ksteps, hh->bufs[hh->s_splitk].bytes);
             const int tile = pl.tile, splitk = pl.splitk;
             if (splitk == 1) {
                 c.splitk = 1;
@@ -1934,6 +1937,7 @@ extern "C" int bndm_unet_sample_iadb(bndm_unet *h, float *x, const float *extra_
         float *xk = x + (size_t)k * Bl * per;
         float *tbuf = (float *)h->P(h->s_t), *dbuf = (float *)h->P(h->s_d);
         RunCtx r{Bl, sk, xk, extra_in ? extra_in + (size_t)k * Bl * per : nullptr, tbuf, dbuf};
+        r.chains = lf.n;
         if (h->f32) hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(64), 0, sk, tbuf, t_in[s], Bl);
         else r.tp_row = h->tp_table + (size_t)s * h->ntemb;
         int e = run_forward(h, r);
@@ -1971,6 +1975,7 @@ extern "C" int bndm_unet_sample_ddim(bndm_unet *h, float *x, int B, int nb_step,
         float *xk = x + (size_t)k * Bl * per;
         float *tbuf = (float *)h->P(h->s_t), *dbuf = (float *)h->P(h->s_d);
         RunCtx r{Bl, sk, xk, nullptr, tbuf, dbuf};
+        r.chains = lf.n;
         if (h->f32) hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(64), 0, sk, tbuf, c[0], Bl);
         else r.tp_row = h->tp_table + (size_t)s * h->ntemb;
         const int e = run_forward(h, r);
