@@ -3,10 +3,14 @@
 # product sources (works in a scratch copy of bndm_amd/csrc):  tools/lib_v6.so (pair-granular GroupNorm sums + sums-first
 # prologue + TH=32 path, = the round-4 patch), tools/lib_v8.so (the same library, TH=32 selected by BNDM_TH32_MIN at run time),
 # tools/lib_v7.so (+ scalar chunk descriptors).
+# tools/lib_v9.so: the product sources + conv_t32's staged 1x1 (shortcut) chunks (conv_t32_shortcut_stages.patch) -- bit-identical
+# to the shipped library by construction (tools/fwd_hash.py).
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); T=$(mktemp -d); mkdir -p $T/bndm_amd $T/include
-cp -r $R/bndm_amd/csrc $T/bndm_amd/; cp $R/include/*.h $T/include/
-cd $T && git init -q . && git apply $R/tools/experiments/round4_pairstats_sumsfirst_th32.patch
+cp -r $R/bndm_amd/csrc $T/bndm_amd/; cp $R/include/*.h $T/include/; rm -f $T/bndm_amd/csrc/*.o
+cd $T && git init -q . && git apply $R/tools/experiments/conv_t32_shortcut_stages.patch && make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v9.so
+git apply -R $R/tools/experiments/conv_t32_shortcut_stages.patch
+git apply $R/tools/experiments/round4_pairstats_sumsfirst_th32.patch
 make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v8.so && cp bndm_amd/libbndm_hip.so $R/tools/lib_v6.so
 git apply $R/tools/experiments/conv_t32_scalar_chunks.patch && make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v7.so
-rm -rf $T; ls -la $R/tools/lib_v[678].so
+rm -rf $T; ls -la $R/tools/lib_v[6789].so
