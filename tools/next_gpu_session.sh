@@ -17,6 +17,9 @@ import json,sys
 d=json.loads(sys.stdin.read()); o=d.get('other_configs') or {}
 print('   c2', d['value'], 'images/s;', {k:(v['value'], v['ms_per_forward']) for k,v in o.items()})"
 done
+echo "-- kernel trace of a 4-lane run: how much of the time kernels of more than one queue are in flight"
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --output-format csv --kernel-trace -d $R/gpurun_out/lanes_kt -- python $R/bench.py --lanes 4 --steps 1 --warmup 1 --nb_steps 25 --no-cpu-baseline --no-other-configs > $R/gpurun_out/lanes_kt.log 2>&1)
+python tools/overlap.py gpurun_out/lanes_kt 2>&1 | tee gpurun_out/lanes_overlap.txt | head -20; rm -rf gpurun_out/lanes_kt
 echo "== 3. staged 1x1 (shortcut) chunks: must hash like the shipped library (c2 and c4), then A/B"
 for c in c2 c4; do python tools/fwd_hash.py bndm_amd/libbndm_hip.so $c 2>&1 | tail -1; python tools/fwd_hash.py tools/lib_v9.so $c 2>&1 | tail -1; done
 echo "== 3a. A/B: shipped vs candidates (per-op profile, accuracy vs the fp32 mode)"
