@@ -37,6 +37,11 @@ def main():
     ap.add_argument("--handle-batch", default="full", choices=["full", "lane"],
                     help="max_batch of a chain's engine handle: tile sizes are chosen from it at build time.  'full' keeps the "
                          "B-sample choices (bit-identical results expected), 'lane' lets the engine choose for B / lanes")
+    ap.add_argument("--cumask", action="store_true",
+                    help="host-thread form on streams with disjoint CU masks (hipExtStreamCreateWithCUMask): chain k gets the "
+                         "k-th 32 / lanes bits of every 32-bit mask word, i.e. an equal share of CUs that leaves no XCD empty under "
+                         "either bit numbering.  The chains then cannot share a CU, but the chip-wide prologue / epilogue bursts of "
+                         "one share run beside the K loops of the other")
     a = ap.parse_args()
     from bndm_amd import _lib
     if a.lib:
@@ -51,7 +56,21 @@ def main():
     params = torch.tensor([1000.0, 0.0, 3.0], device=dev)
     full = get_model(3, 6, R, dtype="f16", seed=0).to(dev).eval()
     lanes = [get_model(3, 6, R, dtype="f16", seed=0).to(dev).eval() for _ in range(NL)]      # same seed = same weights
-    streams = [torch.cuda.Stream(device=dev) for _ in range(NL)]
+    def masked_stream(k):
+        import ctypes
+        path = next((ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln), "libamdhip64.so")
+        hip = ctypes.CDLL(path)                                 # the runtime torch itself has loaded
+        per = 32 // NL
+        word = ((1 << per) - 1) << (k * per)
+        words = (ctypes.c_uint32 * 8)(*([word] * 8))            # 256 CUs
+        st = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
+        if rc != 0:
+            raise SystemExit(f"hipExtStreamCreateWithCUMask failed: {rc}")
+        return torch.cuda.ExternalStream(st.value, device=dev)
+
+    torch.zeros(1, device=dev)                                  # (runtime loaded and initialised)
+    streams = [masked_stream(k) if a.cumask else torch.cuda.Stream(device=dev) for k in range(NL)]
     g = torch.Generator().manual_seed(3)
     x0 = torch.randn(B, 3, R, R, generator=g).to(dev)
     hb = B // NL
