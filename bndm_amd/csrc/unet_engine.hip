@@ -168,8 +168,13 @@ struct bndm_unet {
     // enqueued step by step by the calling thread, or (lane_threads) by one host thread per chain.
     int nlanes = 1;
     bool lane_threads = false;
-    std::vector<hipStream_t> lane_st;    // streams of lanes 1.. (lane 0 runs on the caller's stream)
-    std::vector<hipEvent_t> lane_ev;     // [0] fork (caller's stream), [1..] join (lane streams)
+    // lane_cus: every chain (lane 0 too) runs on a stream of the handle created with a CU mask -- chain k gets the k-th
+    // 32 / nlanes bits of every mask word, an equal share of the CUs that leaves no XCD empty.  The chains then never share a
+    // CU; what they share is the memory system, where the chip-wide prologue / epilogue bursts of one share now run beside
+    // the K loops of the others (those bursts are at the HBM rate).
+    bool lane_cus = false;
+    std::vector<hipStream_t> lane_st;    // [k - 1]: stream of lane k >= 1 (lane 0 runs on the caller's stream); lane_cus: [k]
+    std::vector<hipEvent_t> lane_ev;     // [0] fork (caller's stream), [1 + k] join of lane_st[k]
 
     int dtype() const { return cfg.dtype; }
     int new_slot(size_t bytes) {
@@ -1623,10 +1628,10 @@ struct LaneFork {
         n = (!hh->f32 && hh->nlanes > 1 && B % hh->nlanes == 0) ? hh->nlanes : 1;
         if (n == 1) return 0;
         BNDM_CHECK_HIP(hipEventRecord(h->lane_ev[0], st));
-        for (int k = 1; k < n; ++k) BNDM_CHECK_HIP(hipStreamWaitEvent(h->lane_st[k - 1], h->lane_ev[0], 0));
+        for (size_t i = 0; i < h->lane_st.size(); ++i) BNDM_CHECK_HIP(hipStreamWaitEvent(h->lane_st[i], h->lane_ev[0], 0));
         return 0;
     }
-    hipStream_t stream(int k) const { return k ? h->lane_st[k - 1] : st; }
+    hipStream_t stream(int k) const { return n == 1 ? st : h->lane_cus ? h->lane_st[k] : k ? h->lane_st[k - 1] : st; }
     // step(k, s): enqueue step s of chain k on stream(k).  One thread walks the steps and deals every step to the chains
     // in turn, or (lane_threads) every chain gets a host thread of its own that walks all steps.
     int run(int nsteps, const std::function<int(int, int)> &step) {
@@ -1667,9 +1672,10 @@ struct LaneFork {
         return 0;
     }
     int close() {
-        for (int k = 1; k < n; ++k) {
-            BNDM_CHECK_HIP(hipEventRecord(h->lane_ev[k], h->lane_st[k - 1]));
-            BNDM_CHECK_HIP(hipStreamWaitEvent(st, h->lane_ev[k], 0));
+        if (n == 1) return 0;
+        for (size_t i = 0; i < h->lane_st.size(); ++i) {
+            BNDM_CHECK_HIP(hipEventRecord(h->lane_ev[1 + i], h->lane_st[i]));
+            BNDM_CHECK_HIP(hipStreamWaitEvent(st, h->lane_ev[1 + i], 0));
         }
         return 0;
     }
@@ -1819,7 +1825,7 @@ extern "C" int bndm_unet_load_param(bndm_unet *h, const char *name, const float 
     return 0;
 }
 
-extern "C" int bndm_unet_set_lanes(bndm_unet *h, int lanes, int host_threads) {
+extern "C" int bndm_unet_set_lanes(bndm_unet *h, int lanes, int flags) {
     BNDM_REQUIRE(h, "bndm_unet_set_lanes: NULL handle");
     BNDM_REQUIRE(lanes >= 1 && lanes <= 4, "bndm_unet_set_lanes: %d lanes (1..4)", lanes);
     BNDM_REQUIRE(h->kind == 0 && h->cfg.dtype != BNDM_DTYPE_F32, "bndm_unet_set_lanes: UNet handles in f16 / bf16 only");
@@ -1828,7 +1834,8 @@ extern "C" int bndm_unet_set_lanes(bndm_unet *h, int lanes, int host_threads) {
         return BNDM_E_STATE;
     }
     h->nlanes = lanes;
-    h->lane_threads = host_threads != 0 && lanes > 1;
+    h->lane_threads = (flags & 1) != 0 && lanes > 1;
+    h->lane_cus = (flags & 2) != 0 && lanes > 1;
     return 0;
 }
 
@@ -1885,9 +1892,18 @@ extern "C" int bndm_unet_finalize(bndm_unet *h) {
         BNDM_CHECK_HIP(hipMalloc(&bf.ptr, nb ? nb : 16));
     }
     if (h->nlanes > 1) {
-        h->lane_st.assign(h->nlanes - 1, nullptr);
-        h->lane_ev.assign(h->nlanes, nullptr);
-        for (hipStream_t &s : h->lane_st) BNDM_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        h->lane_st.assign(h->lane_cus ? h->nlanes : h->nlanes - 1, nullptr);
+        h->lane_ev.assign(1 + h->lane_st.size(), nullptr);
+        if (h->lane_cus) {
+            const int per = 32 / h->nlanes;
+            for (int k = 0; k < h->nlanes; ++k) {
+                uint32_t words[8];                                      // 256 CUs
+                for (uint32_t &wd : words) wd = (uint32_t)(((1ull << per) - 1) << (k * per));
+                BNDM_CHECK_HIP(hipExtStreamCreateWithCUMask(&h->lane_st[k], 8, words));
+            }
+        } else {
+            for (hipStream_t &s : h->lane_st) BNDM_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        }
         for (hipEvent_t &e : h->lane_ev) BNDM_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     for (auto &fn : b.post_alloc)

@@ -138,10 +138,11 @@ int  bndm_unet_load_param(bndm_unet *h, const char *name, const float *host_data
  * prologues and epilogues are another chain's MFMA time.  Samples are independent (GroupNorm / attention are per
  * sample), so results are bit-identical to one lane; to the caller the loop stays one in-order piece of work on `stream`.
  * Applies when B is a multiple of `lanes`, else the loop runs as one chain.  Before bndm_unet_finalize only.
- * host_threads 0: the calling thread enqueues every chain, step by step; non-zero: one host thread per chain for the
- * duration of a sampling call (twice the launch rate when the host is the limit).
+ * flags: bit 0 -- one host thread per chain for the duration of a sampling call instead of the calling thread dealing
+ * every step to the chains in turn (more launches per second when the host is the limit); bit 1 -- every chain on a
+ * stream with its own CU mask (an equal, disjoint share of the CUs of every XCD) instead of sharing all CUs.
  * The reference's counterpart is torch.nn.DataParallel's batch split (iadb_bn.py:716), here inside one GPU. */
-int  bndm_unet_set_lanes(bndm_unet *h, int lanes, int host_threads);
+int  bndm_unet_set_lanes(bndm_unet *h, int lanes, int flags);
 /* all parameters present -> pack derived tables; must precede forward */
 int  bndm_unet_finalize(bndm_unet *h);
 

@@ -102,8 +102,8 @@ def main():
             cur.wait_stream(s)
         return torch.cat(out, 0)
 
-    eng = get_model(3, 6, R, dtype="f16", seed=0, lanes=NL).to(dev).eval()      # the product form: chains inside the engine
-    engt = get_model(3, 6, R, dtype="f16", seed=0, lanes=NL, lane_threads=True).to(dev).eval()   # ... one host thread per chain
+    eng = get_model(3, 6, R, dtype="f16", seed=0, lanes=NL, lane_cus=a.cumask).to(dev).eval()      # the product form: chains inside the engine
+    engt = get_model(3, 6, R, dtype="f16", seed=0, lanes=NL, lane_threads=True, lane_cus=a.cumask).to(dev).eval()   # ... one host thread per chain
 
     def in_engine():
         return sample_iadb(eng, x0, N, "sigmoid", params, 6, "gaussianBN", "train")
