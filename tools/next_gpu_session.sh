@@ -13,7 +13,7 @@ python tools/two_stream.py --passes 2 --nb_steps 100 --lanes 4 2>&1 | tail -5
 echo "-- chains on disjoint CU shares (host-thread form only; the line to read is the 'streams' one)"
 timeout 600 python tools/two_stream.py --passes 2 --nb_steps 100 --lanes 2 --cumask 2>&1 | tail -5
 timeout 600 python tools/two_stream.py --passes 2 --nb_steps 100 --lanes 4 --cumask 2>&1 | tail -5
-for n in 1 2 4; do
+for n in "1" "2" "4" "2 --lane-cus" "4 --lane-cus" "4 --lane-threads"; do
   echo "-- bench.py --lanes $n"
   python bench.py --lanes $n --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import json,sys
