@@ -109,6 +109,8 @@ struct RunCtx {
     // shared by every sample (batch stride 0); nullptr -> computed per forward from `timesteps`
     const float *tp_row = nullptr;
     int chains = 1;                 // chains of launches in flight side by side (lanes): grid-size heuristics see the sum
+    // lanes: events to record on `st` right behind given ops of this forward (the start marks of the chains behind this one)
+    const std::vector<std::pair<int, hipEvent_t>> *marks = nullptr;
     // profiling
     bool prof = false;
     std::vector<hipEvent_t> *ev = nullptr;
@@ -173,6 +175,12 @@ struct bndm_unet {
     // CU; what they share is the memory system, where the chip-wide prologue / epilogue bursts of one share now run beside
     // the K loops of the others (those bursts are at the HBM rate).
     bool lane_cus = false;
+    // lane_stagger (default with lanes): chain k starts when chain 0 is k / nlanes of the way through its first forward.
+    // Chains that start together run the same kernels on the same amount of data and can stay in lockstep -- two
+    // co-resident workgroups in the same phase again, from two queues; offset by a fraction of a forward, one chain's
+    // MFMA-bound 64x64 levels run beside another chain's launch-bound <= 8x8 section.
+    bool lane_stagger = true;
+    std::vector<hipEvent_t> lane_sev;    // start marks of lanes 1..
     std::vector<hipStream_t> lane_st;    // [k - 1]: stream of lane k >= 1 (lane 0 runs on the caller's stream); lane_cus: [k]
     std::vector<hipEvent_t> lane_ev;     // [0] fork (caller's stream), [1 + k] join of lane_st[k]
 
@@ -1567,6 +1575,9 @@ int run_forward(bndm_unet *h, RunCtx &r) {
         int e = h->ops[i].run(r);
         if (e) return e;
         if (r.prof) BNDM_CHECK_HIP(hipEventRecord((*r.ev)[2 * i + 1], r.st));
+        if (r.marks)
+            for (const auto &m : *r.marks)
+                if (m.first == (int)i) BNDM_CHECK_HIP(hipEventRecord(m.second, r.st));
     }
     return 0;
 }
@@ -1632,12 +1643,42 @@ struct LaneFork {
         return 0;
     }
     hipStream_t stream(int k) const { return n == 1 ? st : h->lane_cus ? h->lane_st[k] : k ? h->lane_st[k - 1] : st; }
+    std::vector<std::pair<int, hipEvent_t>> marks;       // (op of chain 0's first forward, start mark of a later chain)
+    const std::vector<std::pair<int, hipEvent_t>> *marks_for(int k, int s) const { return k == 0 && s == 0 && !marks.empty() ? &marks : nullptr; }
+    // op of a forward at which the fraction f of its (estimated) duration has passed: algorithmic flops at ~1 PFLOP/s plus a
+    // fixed cost per launch -- a start offset only has to be roughly right
+    int op_at(double f, int Bl) const {
+        std::vector<double> w;
+        double tot = 0;
+        for (const Op &o : h->ops) {
+            w.push_back(o.flops_per_sample * Bl * 1e-15 + 8e-6);
+            tot += w.back();
+        }
+        double acc = 0;
+        for (size_t i = 0; i < w.size(); ++i) {
+            acc += w[i];
+            if (acc >= f * tot) return (int)i;
+        }
+        return (int)w.size() - 1;
+    }
     // step(k, s): enqueue step s of chain k on stream(k).  One thread walks the steps and deals every step to the chains
     // in turn, or (lane_threads) every chain gets a host thread of its own that walks all steps.
-    int run(int nsteps, const std::function<int(int, int)> &step) {
-        int rc = 0;
+    int run(int nsteps, int Bl, const std::function<int(int, int)> &step) {
+        int rc = 0, first = 0;
+        if (n > 1 && nsteps > 0 && h->lane_stagger) {
+            // step 0 of every chain by this thread: chain 0 records the start marks, chain k waits for its mark
+            for (int k = 1; k < n; ++k) marks.emplace_back(op_at((double)k / n, Bl), h->lane_sev[k - 1]);
+            for (int k = 0; k < n && !rc; ++k) {
+                t_lane = k;
+                if (k) BNDM_CHECK_HIP(hipStreamWaitEvent(stream(k), h->lane_sev[k - 1], 0));
+                rc = step(k, 0);
+            }
+            t_lane = 0;
+            if (rc) return rc;
+            first = 1;
+        }
         if (n == 1 || !h->lane_threads) {
-            for (int s = 0; s < nsteps && !rc; ++s)
+            for (int s = first; s < nsteps && !rc; ++s)
                 for (int k = 0; k < n && !rc; ++k) {
                     t_lane = k;
                     rc = step(k, s);
@@ -1656,7 +1697,7 @@ struct LaneFork {
                 msgs[k] = "lane thread: hipSetDevice failed";
                 return;
             }
-            for (int s = 0; s < nsteps && !rcs[k]; ++s) rcs[k] = step(k, s);
+            for (int s = first; s < nsteps && !rcs[k]; ++s) rcs[k] = step(k, s);
             if (rcs[k]) msgs[k] = bndm_last_error();                    // the error text is per thread
             t_lane = 0;
         };
@@ -1794,6 +1835,8 @@ extern "C" void bndm_unet_destroy(bndm_unet *h) {
         }
     for (hipEvent_t e : h->lane_ev)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->lane_sev)
+        if (e) (void)hipEventDestroy(e);
     if (h->f32) f32_model_destroy(h->f32);
     for (Buf &b : h->bufs)
         if (b.ptr) (void)hipFree(b.ptr);
@@ -1836,6 +1879,7 @@ extern "C" int bndm_unet_set_lanes(bndm_unet *h, int lanes, int flags) {
     h->nlanes = lanes;
     h->lane_threads = (flags & 1) != 0 && lanes > 1;
     h->lane_cus = (flags & 2) != 0 && lanes > 1;
+    h->lane_stagger = (flags & 4) == 0;
     return 0;
 }
 
@@ -1905,6 +1949,8 @@ extern "C" int bndm_unet_finalize(bndm_unet *h) {
             for (hipStream_t &s : h->lane_st) BNDM_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         }
         for (hipEvent_t &e : h->lane_ev) BNDM_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->lane_sev.assign(h->nlanes - 1, nullptr);
+        for (hipEvent_t &e : h->lane_sev) BNDM_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     for (auto &fn : b.post_alloc)
         if ((rc = fn())) return rc;
@@ -1948,12 +1994,13 @@ extern "C" int bndm_unet_sample_iadb(bndm_unet *h, float *x, const float *extra_
     if (snap_mask && snapshots)
         for (int s = 0, n = 0; s < nb_step; ++s)
             if (snap_mask[s]) snap_at[s] = n++;
-    rc = lf.run(nb_step, [&](int k, int s) -> int {
+    rc = lf.run(nb_step, Bl, [&](int k, int s) -> int {
         hipStream_t sk = lf.stream(k);
         float *xk = x + (size_t)k * Bl * per;
         float *tbuf = (float *)h->P(h->s_t), *dbuf = (float *)h->P(h->s_d);
         RunCtx r{Bl, sk, xk, extra_in ? extra_in + (size_t)k * Bl * per : nullptr, tbuf, dbuf};
         r.chains = lf.n;
+        r.marks = lf.marks_for(k, s);
         if (h->f32) hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(64), 0, sk, tbuf, t_in[s], Bl);
         else r.tp_row = h->tp_table + (size_t)s * h->ntemb;
         int e = run_forward(h, r);
@@ -1985,13 +2032,14 @@ extern "C" int bndm_unet_sample_ddim(bndm_unet *h, float *x, int B, int nb_step,
     if ((rc = lf.open(h, B, st))) return rc;
     const int Bl = B / lf.n;
     const size_t per = (size_t)h->cfg.in_channels * R * R;
-    rc = lf.run(nb_step, [&](int k, int s) -> int {
+    rc = lf.run(nb_step, Bl, [&](int k, int s) -> int {
         const float *c = coef + 5 * s;
         hipStream_t sk = lf.stream(k);
         float *xk = x + (size_t)k * Bl * per;
         float *tbuf = (float *)h->P(h->s_t), *dbuf = (float *)h->P(h->s_d);
         RunCtx r{Bl, sk, xk, nullptr, tbuf, dbuf};
         r.chains = lf.n;
+        r.marks = lf.marks_for(k, s);
         if (h->f32) hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(64), 0, sk, tbuf, c[0], Bl);
         else r.tp_row = h->tp_table + (size_t)s * h->ntemb;
         const int e = run_forward(h, r);

@@ -140,7 +140,9 @@ int  bndm_unet_load_param(bndm_unet *h, const char *name, const float *host_data
  * Applies when B is a multiple of `lanes`, else the loop runs as one chain.  Before bndm_unet_finalize only.
  * flags: bit 0 -- one host thread per chain for the duration of a sampling call instead of the calling thread dealing
  * every step to the chains in turn (more launches per second when the host is the limit); bit 1 -- every chain on a
- * stream with its own CU mask (an equal, disjoint share of the CUs of every XCD) instead of sharing all CUs.
+ * stream with its own CU mask (an equal, disjoint share of the CUs of every XCD) instead of sharing all CUs; bit 2 --
+ * no start offsets (by default chain k starts when chain 0 is k / lanes of the way through its first forward, so that
+ * the chains do not run the same kernel at the same time).
  * The reference's counterpart is torch.nn.DataParallel's batch split (iadb_bn.py:716), here inside one GPU. */
 int  bndm_unet_set_lanes(bndm_unet *h, int lanes, int flags);
 /* all parameters present -> pack derived tables; must precede forward */

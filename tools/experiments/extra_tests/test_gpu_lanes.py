@@ -73,6 +73,16 @@ def test_benched_batch_two_lanes_and_forward_still_one_lane():
     assert torch.equal(m1(x0, t, return_dict=False)[0], m2(x0, t, return_dict=False)[0])
 
 
+def test_no_stagger_bit_identical():
+    from bndm_amd.sampler import get_model, sample_iadb
+    m1 = get_model(3, 6, 64, seed=5).cuda().eval()
+    m2 = get_model(3, 6, 64, seed=5, lanes=4, lane_stagger=False).cuda().eval()
+    x0 = torch.randn(8, 3, 64, 64, generator=torch.Generator().manual_seed(11)).cuda()
+    p = torch.tensor([1000.0, 0.0, 3.0], device="cuda")
+    assert torch.equal(sample_iadb(m1, x0, 4, "sigmoid", p, 6, "gaussianBN", "train"),
+                       sample_iadb(m2, x0, 4, "sigmoid", p, 6, "gaussianBN", "train"))
+
+
 def test_cu_share_lanes_bit_identical():
     from bndm_amd.sampler import get_model, sample_iadb
     m1 = get_model(3, 6, 64, seed=5).cuda().eval()

@@ -10,6 +10,7 @@ echo "== 2. lanes (bndm_unet_set_lanes): parked tests, then one stream vs host-t
 python -m pytest tools/experiments/extra_tests/test_gpu_lanes.py -m gpu -q -x 2>&1 | tail -5
 python tools/two_stream.py --passes 2 --nb_steps 100 2>&1 | tail -5
 python tools/two_stream.py --passes 2 --nb_steps 100 --lanes 4 2>&1 | tail -5
+python tools/two_stream.py --passes 2 --nb_steps 100 --lanes 4 --no-stagger 2>&1 | tail -3
 echo "-- chains on disjoint CU shares (host-thread form only; the line to read is the 'streams' one)"
 timeout 600 python tools/two_stream.py --passes 2 --nb_steps 100 --lanes 2 --cumask 2>&1 | tail -5
 timeout 600 python tools/two_stream.py --passes 2 --nb_steps 100 --lanes 4 --cumask 2>&1 | tail -5

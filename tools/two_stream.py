@@ -42,6 +42,7 @@ def main():
                          "k-th 32 / lanes bits of every 32-bit mask word, i.e. an equal share of CUs that leaves no XCD empty under "
                          "either bit numbering.  The chains then cannot share a CU, but the chip-wide prologue / epilogue bursts of "
                          "one share run beside the K loops of the other")
+    ap.add_argument("--no-stagger", action="store_true", help="in-engine forms: all chains start together")
     a = ap.parse_args()
     from bndm_amd import _lib
     if a.lib:
@@ -102,8 +103,8 @@ def main():
             cur.wait_stream(s)
         return torch.cat(out, 0)
 
-    eng = get_model(3, 6, R, dtype="f16", seed=0, lanes=NL, lane_cus=a.cumask).to(dev).eval()      # the product form: chains inside the engine
-    engt = get_model(3, 6, R, dtype="f16", seed=0, lanes=NL, lane_threads=True, lane_cus=a.cumask).to(dev).eval()   # ... one host thread per chain
+    eng = get_model(3, 6, R, dtype="f16", seed=0, lanes=NL, lane_cus=a.cumask, lane_stagger=not a.no_stagger).to(dev).eval()      # the product form: chains inside the engine
+    engt = get_model(3, 6, R, dtype="f16", seed=0, lanes=NL, lane_threads=True, lane_cus=a.cumask, lane_stagger=not a.no_stagger).to(dev).eval()   # ... one host thread per chain
 
     def in_engine():
         return sample_iadb(eng, x0, N, "sigmoid", params, 6, "gaussianBN", "train")
