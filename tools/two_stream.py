@@ -42,7 +42,9 @@ def main():
                          "k-th 32 / lanes bits of every 32-bit mask word, i.e. an equal share of CUs that leaves no XCD empty under "
                          "either bit numbering.  The chains then cannot share a CU, but the chip-wide prologue / epilogue bursts of "
                          "one share run beside the K loops of the other")
-    ap.add_argument("--no-stagger", action="store_true", help="in-engine forms: all chains start together")
+    ap.add_argument("--no-stagger", action="store_true", help="all chains start together (default: chain k starts k / lanes of "
+                                                              "a forward behind chain 0, so that they do not run in lockstep)")
+    ap.add_argument("--forward-ms", type=float, default=3.0, help="host-thread form: forward time assumed for that offset")
     a = ap.parse_args()
     from bndm_amd import _lib
     if a.lib:
@@ -91,6 +93,8 @@ def main():
         def work(i):
             # one host thread per chain: a sampling call enqueues its whole loop (steps x 95 launches) before it returns,
             # and ctypes drops the GIL inside it
+            if i and not a.no_stagger:
+                time.sleep(i * a.forward_ms * 1e-3 / NL)
             with torch.cuda.device(dev), torch.cuda.stream(streams[i]):
                 streams[i].wait_event(ev)
                 out[i] = sample_iadb(lanes[i], x0[i * hb:(i + 1) * hb], N, "sigmoid", params, 6, "gaussianBN", "train")
