@@ -16,11 +16,11 @@ timeout 600 python tools/two_stream.py --passes 2 --nb_steps 100 --lanes 2 --cum
 timeout 600 python tools/two_stream.py --passes 2 --nb_steps 100 --lanes 4 --cumask 2>&1 | tail -5
 for n in "1" "2" "4" "2 --lane-cus" "4 --lane-cus" "4 --lane-threads"; do
   echo "-- bench.py --lanes $n"
-  python bench.py --lanes $n --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+  python bench.py --lanes $n --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs 2>&1 | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); o=d.get('other_configs') or {}
-print('   c2', d['value'], 'images/s;', {k:(v['value'], v['ms_per_forward']) for k,v in o.items()})"
+d=json.loads(sys.stdin.read()); print('   c2', d['value'], 'images/s', d['ms_per_step'], 'ms per pass')"
 done
+echo "-- (other configurations under the best arrangement: python bench.py --lanes N [--lane-cus] --steps 2 --warmup 1 --no-cpu-baseline)"
 echo "-- kernel trace of a 4-lane run: how much of the time kernels of more than one queue are in flight"
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --output-format csv --kernel-trace -d $R/gpurun_out/lanes_kt -- python $R/bench.py --lanes 4 --steps 1 --warmup 1 --nb_steps 25 --no-cpu-baseline --no-other-configs > $R/gpurun_out/lanes_kt.log 2>&1)
 python tools/overlap.py gpurun_out/lanes_kt 2>&1 | tee gpurun_out/lanes_overlap.txt | head -20; rm -rf gpurun_out/lanes_kt
