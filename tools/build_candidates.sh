@@ -13,4 +13,6 @@ git apply -R $R/tools/experiments/conv_t32_shortcut_stages.patch
 git apply $R/tools/experiments/round4_pairstats_sumsfirst_th32.patch
 make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v8.so && cp bndm_amd/libbndm_hip.so $R/tools/lib_v6.so
 git apply $R/tools/experiments/conv_t32_scalar_chunks.patch && make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v7.so
-rm -rf $T; ls -la $R/tools/lib_v[6789].so
+# tools/lib_v11.so: everything stacked (round-4 patch + scalar chunk descriptors + staged 1x1 chunks)
+git apply $R/tools/experiments/conv_t32_shortcut_stages.patch && make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v11.so
+rm -rf $T; ls -la $R/tools/lib_v[6789].so $R/tools/lib_v11.so

@@ -27,7 +27,7 @@ python tools/overlap.py gpurun_out/lanes_kt 2>&1 | tee gpurun_out/lanes_overlap.
 echo "== 3. staged 1x1 (shortcut) chunks: must hash like the shipped library (c2 and c4), then A/B"
 for c in c2 c4; do python tools/fwd_hash.py bndm_amd/libbndm_hip.so $c 2>&1 | tail -1; python tools/fwd_hash.py tools/lib_v9.so $c 2>&1 | tail -1; done
 echo "== 3a. A/B: shipped vs candidates (per-op profile, accuracy vs the fp32 mode)"
-python tools/ab_libs.py --rounds 2 --acc bndm_amd/libbndm_hip.so tools/lib_v9.so tools/lib_v6.so tools/lib_v7.so "tools/lib_v8.so@BNDM_TH32_MIN=256" 2>&1 | tail -16
+python tools/ab_libs.py --rounds 2 --acc bndm_amd/libbndm_hip.so tools/lib_v9.so tools/lib_v6.so tools/lib_v7.so tools/lib_v11.so "tools/lib_v8.so@BNDM_TH32_MIN=256" 2>&1 | tail -18
 echo "== 4. grid sweep of single conv_t32 launches: shipped TH=16, candidate TH=16 and TH=32"
 tools/ubench/t32_bench.bin 16 1 0
 mkdir -p /tmp/cand && cp tools/lib_v8.so /tmp/cand/libbndm_hip.so
