@@ -10,9 +10,12 @@ R=$(cd "$(dirname "$0")/.." && pwd); T=$(mktemp -d); mkdir -p $T/bndm_amd $T/inc
 cp -r $R/bndm_amd/csrc $T/bndm_amd/; cp $R/include/*.h $T/include/; rm -f $T/bndm_amd/csrc/*.o
 cd $T && git init -q . && git apply $R/tools/experiments/conv_t32_shortcut_stages.patch && make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v9.so
 git apply -R $R/tools/experiments/conv_t32_shortcut_stages.patch
+# tools/lib_v12.so: the product sources + scalar chunk descriptors alone (bit-identical to the shipped library as well)
+git apply $R/tools/experiments/conv_t32_scalar_chunks_on_product.patch && make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v12.so
+git apply -R $R/tools/experiments/conv_t32_scalar_chunks_on_product.patch
 git apply $R/tools/experiments/round4_pairstats_sumsfirst_th32.patch
 make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v8.so && cp bndm_amd/libbndm_hip.so $R/tools/lib_v6.so
 git apply $R/tools/experiments/conv_t32_scalar_chunks.patch && make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v7.so
 # tools/lib_v11.so: everything stacked (round-4 patch + scalar chunk descriptors + staged 1x1 chunks)
 git apply $R/tools/experiments/conv_t32_shortcut_stages.patch && make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v11.so
-rm -rf $T; ls -la $R/tools/lib_v[6789].so $R/tools/lib_v11.so
+rm -rf $T; ls -la $R/tools/lib_v[6789].so $R/tools/lib_v11.so $R/tools/lib_v12.so
