@@ -101,5 +101,5 @@ def test_set_lanes_contract():
     h = m._ensure_engine(2, 64, torch.device("cuda", 0))
     assert lib.bndm_unet_set_lanes(h, 2, 0) == -2                      # BNDM_E_STATE: already finalised
     assert b"finalised" in lib.bndm_last_error()
-    with pytest.raises(_lib.BndmError):
+    with pytest.raises(NotImplementedError):                        # BNDM_E_ARG: 1..4 lanes
         _models((5,))[0]._ensure_engine(2, 64, torch.device("cuda", 0))
