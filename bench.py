@@ -399,6 +399,13 @@ def main():
                 "algorithmic_bytes_per_launch": prof.dom_bytes / max(prof.dom_launches, 1),
                 "all_conv_kernels_tflops": round(conv_all, 1), "ms_per_forward_conv": round(prof.ms_conv, 3),
                 "ms_per_forward_total": round(prof.ms_total, 3), "launches_total": prof.launches}
+        # the whole timed loop against the same peak: algorithmic flops of every launch of a forward x denoising steps x images / s
+        # (with lanes the per-launch figure above is still that of a launch running alone; this one is what the loop sustains)
+        if elapsed == elapsed and elapsed > 0:
+            fwd_flops = sum(f for _, _, f in engine_ops(h))                      # per sample
+            e2e = fwd_flops * N * (B * args.steps / elapsed) / 1e12
+            roof["end_to_end_tflops"] = round(e2e, 1)
+            roof["end_to_end_frac"] = round(e2e / PEAK_F16_TFLOPS, 4)
 
     # ---- per-stage figures: blue-noise transform vs its HBM / fp32-MFMA rooflines -------------
     stages = None
