@@ -13,9 +13,12 @@ git apply -R $R/tools/experiments/conv_t32_shortcut_stages.patch
 # tools/lib_v12.so: the product sources + scalar chunk descriptors alone (bit-identical to the shipped library as well)
 git apply $R/tools/experiments/conv_t32_scalar_chunks_on_product.patch && make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v12.so
 git apply -R $R/tools/experiments/conv_t32_scalar_chunks_on_product.patch
+# tools/lib_v13.so: the product sources + write-back stores for conv_t32 workgroups that are not in the last round (bit-identical)
+git apply $R/tools/experiments/conv_t32_first_round_write_back.patch && make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v13.so
+git apply -R $R/tools/experiments/conv_t32_first_round_write_back.patch
 git apply $R/tools/experiments/round4_pairstats_sumsfirst_th32.patch
 make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v8.so && cp bndm_amd/libbndm_hip.so $R/tools/lib_v6.so
 git apply $R/tools/experiments/conv_t32_scalar_chunks.patch && make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v7.so
 # tools/lib_v11.so: everything stacked (round-4 patch + scalar chunk descriptors + staged 1x1 chunks)
 git apply $R/tools/experiments/conv_t32_shortcut_stages.patch && make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v11.so
-rm -rf $T; ls -la $R/tools/lib_v[6789].so $R/tools/lib_v11.so $R/tools/lib_v12.so
+rm -rf $T; ls -la $R/tools/lib_v[6789].so $R/tools/lib_v11.so $R/tools/lib_v12.so $R/tools/lib_v13.so
