@@ -15,10 +15,14 @@ git apply $R/tools/experiments/conv_t32_scalar_chunks_on_product.patch && make -
 git apply -R $R/tools/experiments/conv_t32_scalar_chunks_on_product.patch
 # tools/lib_v13.so: the product sources + write-back stores for conv_t32 workgroups that are not in the last round (bit-identical)
 git apply $R/tools/experiments/conv_t32_first_round_write_back.patch && make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v13.so
+# tools/lib_v14.so: the three bit-identical candidates stacked on the product sources (v9 + v12 + v13)
+git apply $R/tools/experiments/conv_t32_shortcut_stages.patch && git apply $R/tools/experiments/conv_t32_scalar_chunks_on_product.patch
+make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v14.so
+git apply -R $R/tools/experiments/conv_t32_scalar_chunks_on_product.patch && git apply -R $R/tools/experiments/conv_t32_shortcut_stages.patch
 git apply -R $R/tools/experiments/conv_t32_first_round_write_back.patch
 git apply $R/tools/experiments/round4_pairstats_sumsfirst_th32.patch
 make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v8.so && cp bndm_amd/libbndm_hip.so $R/tools/lib_v6.so
 git apply $R/tools/experiments/conv_t32_scalar_chunks.patch && make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v7.so
 # tools/lib_v11.so: everything stacked (round-4 patch + scalar chunk descriptors + staged 1x1 chunks)
 git apply $R/tools/experiments/conv_t32_shortcut_stages.patch && make -C bndm_amd/csrc -j8 > /dev/null && cp bndm_amd/libbndm_hip.so $R/tools/lib_v11.so
-rm -rf $T; ls -la $R/tools/lib_v[6789].so $R/tools/lib_v11.so $R/tools/lib_v12.so $R/tools/lib_v13.so
+rm -rf $T; ls -la $R/tools/lib_v[6789].so $R/tools/lib_v11.so $R/tools/lib_v12.so $R/tools/lib_v13.so $R/tools/lib_v14.so

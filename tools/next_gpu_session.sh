@@ -25,9 +25,9 @@ echo "-- kernel trace of a 4-lane run: how much of the time kernels of more than
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --output-format csv --kernel-trace -d $R/gpurun_out/lanes_kt -- python $R/bench.py --lanes 4 --steps 1 --warmup 1 --nb_steps 25 --no-cpu-baseline --no-other-configs > $R/gpurun_out/lanes_kt.log 2>&1)
 python tools/overlap.py gpurun_out/lanes_kt 2>&1 | tee gpurun_out/lanes_overlap.txt | head -20; rm -rf gpurun_out/lanes_kt
 echo "== 3. staged 1x1 (shortcut) chunks (v9) and scalar chunk descriptors on the product sources (v12): must hash like the shipped library"
-for c in c2 c4; do for l in bndm_amd/libbndm_hip.so tools/lib_v9.so tools/lib_v12.so tools/lib_v13.so; do echo -n "$l  "; python tools/fwd_hash.py $l $c 2>&1 | tail -1; done; done
+for c in c2 c4; do for l in bndm_amd/libbndm_hip.so tools/lib_v9.so tools/lib_v12.so tools/lib_v13.so tools/lib_v14.so; do echo -n "$l  "; python tools/fwd_hash.py $l $c 2>&1 | tail -1; done; done
 echo "== 3a. A/B: shipped vs candidates (per-op profile, accuracy vs the fp32 mode)"
-python tools/ab_libs.py --rounds 2 --acc bndm_amd/libbndm_hip.so tools/lib_v9.so tools/lib_v12.so tools/lib_v13.so tools/lib_v6.so tools/lib_v7.so tools/lib_v11.so "tools/lib_v8.so@BNDM_TH32_MIN=256" 2>&1 | tail -20
+python tools/ab_libs.py --rounds 2 --acc bndm_amd/libbndm_hip.so tools/lib_v9.so tools/lib_v12.so tools/lib_v13.so tools/lib_v14.so tools/lib_v6.so tools/lib_v7.so tools/lib_v11.so "tools/lib_v8.so@BNDM_TH32_MIN=256" 2>&1 | tail -20
 echo "== 4. grid sweep of single conv_t32 launches: shipped TH=16, candidate TH=16 and TH=32"
 tools/ubench/t32_bench.bin 16 1 0
 mkdir -p /tmp/cand && cp tools/lib_v8.so /tmp/cand/libbndm_hip.so

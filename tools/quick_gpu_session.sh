@@ -8,5 +8,5 @@ echo "== lanes: one stream vs chains (4 lanes; shared CUs, then CU shares)"
 timeout 600 python tools/two_stream.py --passes 2 --nb_steps 60 --lanes 4 2>&1 | tail -5
 timeout 600 python tools/two_stream.py --passes 2 --nb_steps 60 --lanes 4 --cumask 2>&1 | tail -5
 echo "== hashes: shipped / staged 1x1 chunks / scalar chunk descriptors"
-for l in bndm_amd/libbndm_hip.so tools/lib_v9.so tools/lib_v12.so tools/lib_v13.so; do echo -n "$l  "; timeout 300 python tools/fwd_hash.py $l c2 2>&1 | tail -1; done
-echo "== A/B (one round)"; timeout 900 python tools/ab_libs.py --rounds 1 bndm_amd/libbndm_hip.so tools/lib_v9.so tools/lib_v12.so tools/lib_v13.so tools/lib_v11.so 2>&1 | tail -10
+for l in bndm_amd/libbndm_hip.so tools/lib_v9.so tools/lib_v12.so tools/lib_v13.so tools/lib_v14.so; do echo -n "$l  "; timeout 300 python tools/fwd_hash.py $l c2 2>&1 | tail -1; done
+echo "== A/B (one round)"; timeout 900 python tools/ab_libs.py --rounds 1 bndm_amd/libbndm_hip.so tools/lib_v9.so tools/lib_v12.so tools/lib_v13.so tools/lib_v14.so tools/lib_v11.so 2>&1 | tail -10
