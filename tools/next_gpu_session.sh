@@ -34,6 +34,7 @@ mkdir -p /tmp/cand && cp tools/lib_v8.so /tmp/cand/libbndm_hip.so
 LD_LIBRARY_PATH=/tmp/cand tools/ubench/t32_bench.bin 16 1 0
 LD_LIBRARY_PATH=/tmp/cand tools/ubench/t32_bench.bin 32 1 0
 echo "== 4a. can launches of one stream overlap (hipExtAnyOrderLaunch)?"; timeout 60 tools/ubench/anyorder.bin
+echo "== 4a2. producer -> consumer hand-over inside one launch (bounded spin): which load form is coherent across XCDs, and the latency"; timeout 60 tools/ubench/flagwait.bin
 echo "== 4b. never-run extra tests (first-level widths 64 / 256)"
 python -m pytest tools/experiments/extra_tests/test_gpu_first_level_widths.py -m gpu -q 2>&1 | tail -5
 echo "== 5. if a candidate wins: apply its patch, rebuild, then the full suite:  python -m pytest tests -m gpu -x -q"
