@@ -148,7 +148,7 @@ def self_launch(args, argv):
 # -------------------------------------------------------------------------------------------------
 # workloads
 # -------------------------------------------------------------------------------------------------
-def make_workload(name, B, N, dtype, dev, rank=0, world=1, lanes=1, lane_kw=None):
+def make_workload(name, B, N, dtype, dev, rank=0, world=1):
     """-> dict(one_pass, model, res, cin, cout, images_per_pass, metric, workload, extra_stage)
 
     c4 on more than one GPU is the named configuration "batch = world x 32 sharded": the 128-px blue-noise branch permutes
@@ -162,7 +162,6 @@ def make_workload(name, B, N, dtype, dev, rank=0, world=1, lanes=1, lane_kw=None
     from bndm_amd.sampler import export_u8, get_model, sample_iadb
     from bndm_amd.schedules import get_scheduler_gamma
     from bndm_amd.synth import blue_noise_factor
-    lane_kw = dict(lane_kw or {}, lanes=lanes)
 
     if name in ("c2", "c4"):
         res = 64 if name == "c2" else 128
@@ -170,7 +169,7 @@ def make_workload(name, B, N, dtype, dev, rank=0, world=1, lanes=1, lane_kw=None
         N = N or 250
         tau = 1000.0 if name == "c2" else 0.2
         L = torch.from_numpy(blue_noise_factor("blue")).to(dev)
-        model = get_model(3, 6, res, dtype=dtype, seed=0, **lane_kw).to(dev).eval()
+        model = get_model(3, 6, res, dtype=dtype, seed=0).to(dev).eval()
         params = torch.tensor([tau, 0.0, 3.0], device=dev)
         sharded = name == "c4" and world > 1
         BG = B * world if sharded else B                                              # batch the noise branch sees
@@ -204,7 +203,7 @@ def make_workload(name, B, N, dtype, dev, rank=0, world=1, lanes=1, lane_kw=None
     if name == "c3":
         from bndm_amd.schedulers import DDIMScheduler
         B, N = B or 64, N or 100
-        model = get_model(3, 3, 64, dtype=dtype, seed=0, **lane_kw).to(dev).eval()
+        model = get_model(3, 3, 64, dtype=dtype, seed=0).to(dev).eval()
         sch = DDIMScheduler(num_train_timesteps=1000, beta_schedule="linear")
         sch.set_timesteps(N)
 
@@ -224,7 +223,7 @@ def make_workload(name, B, N, dtype, dev, rank=0, world=1, lanes=1, lane_kw=None
         model = UNet2DModel(sample_size=64, in_channels=4, out_channels=8, layers_per_block=2, block_out_channels=boc,
                             down_block_types=tuple("AttnDownBlock2D" if i == 4 else "DownBlock2D" for i in range(6)),
                             up_block_types=tuple("AttnUpBlock2D" if i == 1 else "UpBlock2D" for i in range(6)),
-                            dtype=dtype, seed=0, **lane_kw).to(dev).eval()
+                            dtype=dtype, seed=0).to(dev).eval()
         vae = AutoencoderKL(dtype=dtype).to(dev).eval()
         sch = IADBScheduler(noise_type="gaussianBN", out_channels=8)
         sch.set_timesteps(N)
@@ -244,14 +243,14 @@ def make_workload(name, B, N, dtype, dev, rank=0, world=1, lanes=1, lane_kw=None
     raise SystemExit(f"unknown --config {name}")
 
 
-def short_pass(name, dtype, dev, lib, timed=2, lanes=1, lane_kw=None):
+def short_pass(name, dtype, dev, lib, timed=2):
     """One BASELINE.json configuration at its per-GPU size: 1 warm-up + `timed` passes of the whole path, plus the
     forward's event-timed duration and TFLOP/s (algorithmic 2*MAC of the engine's launch list)."""
     import torch
     from bndm_amd import _lib
     from bndm_amd.unet import engine_ops
     os.environ.pop("BNDM_PROFILE_DUMP", None)    # the per-op dump is the headline workload's, written before this
-    wl = make_workload(name, 0, 0, dtype, dev, lanes=lanes, lane_kw=lane_kw)
+    wl = make_workload(name, 0, 0, dtype, dev)
     B, N, model = wl["B"], wl["N"], wl["model"]
     wl["one_pass"]()
     torch.cuda.synchronize()
@@ -298,11 +297,6 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per pass (default: the configuration's)")
     ap.add_argument("--nb_steps", type=int, default=0, help="denoising steps per image (default: the configuration's)")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
-    ap.add_argument("--lanes", type=int, default=1,
-                    help="sampling loops as this many chains of launches on separate HIP streams inside the engine "
-                         "(bndm_unet_set_lanes; bit-identical results).  Default 1 until measured")
-    ap.add_argument("--lane-threads", action="store_true", help="with --lanes: one host thread per chain")
-    ap.add_argument("--lane-cus", action="store_true", help="with --lanes: every chain on its own share of the CUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-only", action="store_true", help="skip the timed passes; only the per-kernel profile")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -348,8 +342,7 @@ def main():
     lib = _lib.load()
 
     torch.manual_seed(1234 + rank)
-    wl = make_workload(args.config, args.batch, args.nb_steps, args.dtype, dev, rank, world, lanes=args.lanes,
-                       lane_kw=dict(lane_threads=args.lane_threads, lane_cus=args.lane_cus))
+    wl = make_workload(args.config, args.batch, args.nb_steps, args.dtype, dev, rank, world)
     B, N, model = wl["B"], wl["N"], wl["model"]
     metric_name, workload_name = wl["metric"], wl["workload"]
 
@@ -400,7 +393,7 @@ def main():
                 "all_conv_kernels_tflops": round(conv_all, 1), "ms_per_forward_conv": round(prof.ms_conv, 3),
                 "ms_per_forward_total": round(prof.ms_total, 3), "launches_total": prof.launches}
         # the whole timed loop against the same peak: algorithmic flops of every launch of a forward x denoising steps x images / s
-        # (with lanes the per-launch figure above is still that of a launch running alone; this one is what the loop sustains)
+        # (the per-launch figure above is that of the dominant kernel alone; this one is what the loop sustains)
         if elapsed == elapsed and elapsed > 0:
             fwd_flops = sum(f for _, _, f in engine_ops(h))                      # per sample
             e2e = fwd_flops * N * (B * args.steps / elapsed) / 1e12
@@ -466,8 +459,7 @@ def main():
         del wl, model
         torch.cuda.empty_cache()
         for oc in ("c3", "c4", "c5"):
-            others[oc] = short_pass(oc, args.dtype, dev, lib, lanes=args.lanes,
-                                    lane_kw=dict(lane_threads=args.lane_threads, lane_cus=args.lane_cus))
+            others[oc] = short_pass(oc, args.dtype, dev, lib)
             torch.cuda.empty_cache()
         wl = None
 
@@ -482,9 +474,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload_name, "baseline_config": args.config,
-                       "global_batch": B * args.gpus, "nb_steps": N, "parallelism": f"batch-shard x{args.gpus}",
-                       "lanes_per_gpu": args.lanes,
-                       **({"lane_threads": args.lane_threads, "lane_cus": args.lane_cus} if args.lanes > 1 else {})},
+                       "global_batch": B * args.gpus, "nb_steps": N, "parallelism": f"batch-shard x{args.gpus}"},
             "roofline": roof,
             "stages": stages,
             # c3 / c4 / c5 at their per-GPU batch (1 warm-up + 2 timed passes each), same library, same process

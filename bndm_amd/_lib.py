@@ -58,7 +58,6 @@ SIGNATURES = {
     "bndm_unet_num_params": (_i, [_vp]),
     "bndm_unet_param_info": (_i, [_vp, _i, C.c_char_p, _sz, C.POINTER(C.c_int64)]),
     "bndm_unet_load_param": (_i, [_vp, C.c_char_p, _vp, C.c_int64]),
-    "bndm_unet_set_lanes": (_i, [_vp, _i, _i]),
     "bndm_unet_finalize": (_i, [_vp]),
     "bndm_unet_num_ops": (_i, [_vp]),
     "bndm_unet_op_info": (_i, [_vp, _i, C.c_char_p, _sz, C.c_char_p, _sz, C.POINTER(C.c_double)]),

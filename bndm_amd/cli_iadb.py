@@ -57,9 +57,6 @@ def build_parser():
     g.add_argument("--save_noise", action="store_true", help="write noise/noise_batch<B>_idx<i>.npz")
     g.add_argument("--dtype", default="f16", choices=["f16", "bf16"], help="UNet storage / MFMA input type")
     g.add_argument("--root", default=".", help="directory holding bluenoise/, results_gaussianBN/, data/")
-    g.add_argument("--lanes", type=int, default=1,
-                   help="run the sampling loop as this many independent chains of launches inside the GPU (1..4; bit-identical)")
-    g.add_argument("--lane_cus", action="store_true", help="with --lanes: every chain on its own share of the CUs")
     return p
 
 
@@ -133,8 +130,7 @@ def main(argv=None):
             os.makedirs(os.path.join(out_dir, folder, sub), exist_ok=True)
 
     say("===> Start unconditional sampling")
-    model = get_model(3, opt.out_channel, opt.res, activation=opt.activation, dtype=opt.dtype, seed=opt.seed,
-                      lanes=opt.lanes, lane_cus=opt.lane_cus)
+    model = get_model(3, opt.out_channel, opt.res, activation=opt.activation, dtype=opt.dtype, seed=opt.seed)
     ckpt = os.path.join(out_dir, "model.ckpt")
     if os.path.exists(ckpt):
         model.load_state_dict(torch.load(ckpt, map_location="cpu"))

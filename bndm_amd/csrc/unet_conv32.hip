@@ -1101,14 +1101,14 @@ std::vector<float> pack_weights_t32(const FusedSeg *seg, int nseg, int Cout,
     return out;
 }
 
-int launch_conv_t32(int dtype, int TH, const FusedArgs &a, hipStream_t st, int chains) {
+int launch_conv_t32(int dtype, int TH, const FusedArgs &a, hipStream_t st) {
     // two 4-wave workgroups per CU need a grid of at least ~two per CU; smaller grids get 8-wave workgroups
     if (a.out_nchw32) {                              // network head: 32-channel tiles, fp32 NCHW output
         if (dtype == BNDM_DTYPE_F16)
             return TH == 16 ? launch_t32_t<_Float16, 16, 0, 4, 32>(a, st) : launch_t32_t<_Float16, 8, 0, 4, 32>(a, st);
         return TH == 16 ? launch_t32_t<__bf16, 16, 0, 4, 32>(a, st) : launch_t32_t<__bf16, 8, 0, 4, 32>(a, st);
     }
-    const long long nblk = (long long)a.B * (a.H / TH) * (a.W / 16) * (a.Cout / 128) * (chains > 1 ? chains : 1);
+    const long long nblk = (long long)a.B * (a.H / TH) * (a.W / 16) * (a.Cout / 128);
     const int nw = nblk >= 448 ? 4 : 8;
     if (dtype == BNDM_DTYPE_F16) {
 #ifdef BNDM_ABLATION      // profiling builds only (tools/ablate.sh)

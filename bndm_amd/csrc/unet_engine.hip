@@ -18,7 +18,6 @@
 #include <map>
 #include <memory>
 #include <string>
-#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -108,9 +107,6 @@ struct RunCtx {
     // time-embedding projections precomputed for the whole schedule (sampler loops): row of this step,
     // shared by every sample (batch stride 0); nullptr -> computed per forward from `timesteps`
     const float *tp_row = nullptr;
-    int chains = 1;                 // chains of launches in flight side by side (lanes): grid-size heuristics see the sum
-    // lanes: events to record on `st` right behind given ops of this forward (the start marks of the chains behind this one)
-    const std::vector<std::pair<int, hipEvent_t>> *marks = nullptr;
     // profiling
     bool prof = false;
     std::vector<hipEvent_t> *ev = nullptr;
@@ -130,9 +126,6 @@ struct Op {
 };
 
 }  // namespace
-
-// lane whose launches the calling thread is enqueueing (bndm_unet::P resolves buffer slots to that lane's copies)
-static thread_local int t_lane = 0;
 
 struct bndm_unet {
     bndm_unet_config cfg{};
@@ -163,27 +156,6 @@ struct bndm_unet {
     int s_y = -1, s_h1 = -1, s_y2 = -1, s_part = -1, s_ss = -1, s_qkv = -1, s_att = -1, s_splitk = -1;
     int s_actemb = -1, s_tp = -1, s_d = -1, s_t = -1;
 
-    // Lanes (bndm_unet_set_lanes, default 1): the sampling loops cut the batch into `nlanes` chains of launches that share the
-    // weights but own a copy of every activation / scratch slot, and enqueue them on separate streams -- the samples of a
-    // batch are independent, so one chain's kernel boundaries, prologues and epilogues are another chain's K-loop time.
-    // The thread-local `t_lane` selects the copy P() resolves to while a thread enqueues a chain's launches; the chains are
-    // enqueued step by step by the calling thread, or (lane_threads) by one host thread per chain.
-    int nlanes = 1;
-    bool lane_threads = false;
-    // lane_cus: every chain (lane 0 too) runs on a stream of the handle created with a CU mask -- chain k gets the k-th
-    // 32 / nlanes bits of every mask word, an equal share of the CUs that leaves no XCD empty.  The chains then never share a
-    // CU; what they share is the memory system, where the chip-wide prologue / epilogue bursts of one share now run beside
-    // the K loops of the others (those bursts are at the HBM rate).
-    bool lane_cus = false;
-    // lane_stagger (default with lanes): chain k starts when chain 0 is k / nlanes of the way through its first forward.
-    // Chains that start together run the same kernels on the same amount of data and can stay in lockstep -- two
-    // co-resident workgroups in the same phase again, from two queues; offset by a fraction of a forward, one chain's
-    // MFMA-bound 64x64 levels run beside another chain's launch-bound <= 8x8 section.
-    bool lane_stagger = true;
-    std::vector<hipEvent_t> lane_sev;    // start marks of lanes 1..
-    std::vector<hipStream_t> lane_st;    // [k - 1]: stream of lane k >= 1 (lane 0 runs on the caller's stream); lane_cus: [k]
-    std::vector<hipEvent_t> lane_ev;     // [0] fork (caller's stream), [1 + k] join of lane_st[k]
-
     int dtype() const { return cfg.dtype; }
     int new_slot(size_t bytes) {
         bufs.push_back(Buf{bytes, nullptr});
@@ -192,8 +164,7 @@ struct bndm_unet {
     void grow(int slot, size_t bytes) {
         if (bufs[slot].bytes < bytes) bufs[slot].bytes = bytes;
     }
-    static size_t lane_stride(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
-    void *P(int slot) const { return t_lane ? (char *)bufs[slot].ptr + (size_t)t_lane * lane_stride(bufs[slot].bytes) : bufs[slot].ptr; }
+    void *P(int slot) const { return bufs[slot].ptr; }
     const std::vector<float> &hp(const std::string &n) const { return host[pindex.at(n)]; }
 };
 
@@ -514,7 +485,7 @@ struct Builder {
             push(OPC_OTHER, 0, [=](RunCtx &r) {
                 GnSlabSrc sl;
                 if (fused_reduce) {
-                    const ConvPlan pl = plan_conv(r.B * r.chains * HW, C1, q.ksteps, hh->bufs[hh->s_splitk].bytes);   // (as the producer planned)
+                    const ConvPlan pl = plan_conv(r.B * HW, C1, q.ksteps, hh->bufs[hh->s_splitk].bytes);
                     if (pl.splitk > 1) {
                         sl.part = (const float *)hh->P(hh->s_splitk);
                         sl.splitk = pl.splitk;
@@ -655,7 +626,7 @@ struct Builder {
             c.resid = rs >= 0 ? hh->P(rs) : nullptr;
             c.out = head ? (void *)r.out : hh->P(so);
             c.stats = pst >= 0 ? (float *)hh->P(pst) : nullptr;
-            return launch_conv_t32(hh->dtype(), TH, c, r.st, r.chains);
+            return launch_conv_t32(hh->dtype(), TH, c, r.st);
         });
         h->ops[op_index].dominant = TH == 16 && !head;
         h->ops[op_index].kernel = S(head ? "conv_t32<TH=%d,N=32>" : "conv_t32<TH=%d>", TH);
@@ -684,7 +655,7 @@ struct Builder {
         cur_name = S("rdce %-44s C=%-4d %dx%d", "", q.C, q.H, q.W);
         push(OPC_OTHER, 0, [=](RunCtx &r) {
             const int M = r.B * q.H * q.W;
-            const ConvPlan pl = plan_conv(M * r.chains, q.C, q.ksteps, hh->bufs[hh->s_splitk].bytes);   // (as the producer planned)
+            const ConvPlan pl = plan_conv(M, q.C, q.ksteps, hh->bufs[hh->s_splitk].bytes);
             if (pl.splitk == 1) return 0;            // the conv wrote the tensor itself
             ConvArgs c{};
             c.B = r.B;
@@ -767,10 +738,8 @@ struct Builder {
                 c.temb = nullptr;
                 c.temb_off = 0;
             }
-            // tile / split-K are planned for the sum of the chains in flight (lanes): the choice, and with it every summation
-            // order, is that of the one-chain run of the whole batch
             const int M = r.B * c.H * c.W;
-            const ConvPlan pl = plan_conv(M * r.chains, c.Cout, ksteps, hh->bufs[hh->s_splitk].bytes);
+            const ConvPlan pl = plan_conv(M, c.Cout, ksteps, hh->bufs[hh->s_splitk].bytes);
             const int tile = pl.tile, splitk = pl.splitk;
             if (splitk == 1) {
                 c.splitk = 1;
@@ -903,7 +872,7 @@ struct Builder {
         void *dDesc = nullptr, *dRounds = nullptr;
         if ((rc = upload_16(h, plan.wgt, &dW))) return srcs[0].a;
         if ((rc = upload(h, plan.desc.data(), plan.desc.size() * 4, &dDesc))) return srcs[0].a;
-        std::vector<TailRound> rt((size_t)plan.nrounds * h->nlanes);         // one table per lane (source pointers)
+        std::vector<TailRound> rt(plan.nrounds);
         if ((rc = upload(h, rt.data(), rt.size() * sizeof(TailRound), &dRounds))) return srcs[0].a;
         {
             std::vector<int> slots;
@@ -911,23 +880,17 @@ struct Builder {
             const std::vector<TailPlanRound> pr = plan.rounds;
             std::vector<int> cs;
             for (const TSrc &t : srcs) cs.push_back(t.a.C);
-            const size_t nr = (size_t)plan.nrounds;                    // (= pr.size(); the launch indexes lanes by nrounds)
             post_alloc.push_back([=]() {
-                std::vector<TailRound> tab(nr * hh->nlanes);
-                for (int ln = 0; ln < hh->nlanes; ++ln) {
-                    t_lane = ln;
-                    for (size_t i = 0; i < pr.size() && i < nr; ++i) {
-                        TailRound &t = tab[ln * nr + i];
-                        t.src = hh->P(slots[pr[i].seg]);
-                        t.row_bytes = cs[pr[i].seg] * 2;
-                        t.cbyte = pr[i].c0 * 2;
-                        t.mode = pr[i].mode;
-                        t.phase = pr[i].phase;
-                        t.nsub = pr[i].nsub;
-                        t.pad = 0;
-                    }
+                std::vector<TailRound> tab(pr.size());
+                for (size_t i = 0; i < pr.size(); ++i) {
+                    tab[i].src = hh->P(slots[pr[i].seg]);
+                    tab[i].row_bytes = cs[pr[i].seg] * 2;
+                    tab[i].cbyte = pr[i].c0 * 2;
+                    tab[i].mode = pr[i].mode;
+                    tab[i].phase = pr[i].phase;
+                    tab[i].nsub = pr[i].nsub;
+                    tab[i].pad = 0;
                 }
-                t_lane = 0;
                 BNDM_CHECK_HIP(hipMemcpy(dRounds, tab.data(), tab.size() * sizeof(TailRound), hipMemcpyHostToDevice));
                 return 0;
             });
@@ -967,7 +930,6 @@ struct Builder {
         push(OPC_CONV, 2.0 * mac * rows * HW + (qkv ? 4.0 * HW * HW * Cout : 0.0), [=](RunCtx &r) {
             TailArgs c = a;
             c.B = r.B;
-            c.rounds = a.rounds + (size_t)t_lane * a.nrounds;
             for (size_t i = 0; i < prs.size(); ++i) {
                 TailRound &d = i ? c.r1 : c.r0;
                 d = TailRound{hh->P(rslots[prs[i].seg]), rcs[prs[i].seg] * 2, prs[i].c0 * 2, prs[i].mode, prs[i].phase,
@@ -1575,9 +1537,6 @@ int run_forward(bndm_unet *h, RunCtx &r) {
         int e = h->ops[i].run(r);
         if (e) return e;
         if (r.prof) BNDM_CHECK_HIP(hipEventRecord((*r.ev)[2 * i + 1], r.st));
-        if (r.marks)
-            for (const auto &m : *r.marks)
-                if (m.first == (int)i) BNDM_CHECK_HIP(hipEventRecord(m.second, r.st));
     }
     return 0;
 }
@@ -1625,102 +1584,6 @@ int check_ready(const bndm_unet *h, int B, const char *what) {
     }
     return 0;
 }
-
-// Fork / join of the sampling loops' chains (bndm_unet::nlanes): lane 0 stays on the caller's stream, lanes 1.. run on the
-// handle's own streams, which wait for everything the caller's stream holds at the fork and are waited for at the join --
-// to the caller the loop is still one in-order piece of work on `st`.
-struct LaneFork {
-    bndm_unet *h = nullptr;
-    hipStream_t st = nullptr;
-    int n = 1;
-    int open(bndm_unet *hh, int B, hipStream_t s) {
-        h = hh;
-        st = s;
-        n = (!hh->f32 && hh->nlanes > 1 && B % hh->nlanes == 0) ? hh->nlanes : 1;
-        if (n == 1) return 0;
-        BNDM_CHECK_HIP(hipEventRecord(h->lane_ev[0], st));
-        for (size_t i = 0; i < h->lane_st.size(); ++i) BNDM_CHECK_HIP(hipStreamWaitEvent(h->lane_st[i], h->lane_ev[0], 0));
-        return 0;
-    }
-    hipStream_t stream(int k) const { return n == 1 ? st : h->lane_cus ? h->lane_st[k] : k ? h->lane_st[k - 1] : st; }
-    std::vector<std::pair<int, hipEvent_t>> marks;       // (op of chain 0's first forward, start mark of a later chain)
-    const std::vector<std::pair<int, hipEvent_t>> *marks_for(int k, int s) const { return k == 0 && s == 0 && !marks.empty() ? &marks : nullptr; }
-    // op of a forward at which the fraction f of its (estimated) duration has passed: algorithmic flops at ~1 PFLOP/s plus a
-    // fixed cost per launch -- a start offset only has to be roughly right
-    int op_at(double f, int Bl) const {
-        std::vector<double> w;
-        double tot = 0;
-        for (const Op &o : h->ops) {
-            w.push_back(o.flops_per_sample * Bl * 1e-15 + 8e-6);
-            tot += w.back();
-        }
-        double acc = 0;
-        for (size_t i = 0; i < w.size(); ++i) {
-            acc += w[i];
-            if (acc >= f * tot) return (int)i;
-        }
-        return (int)w.size() - 1;
-    }
-    // step(k, s): enqueue step s of chain k on stream(k).  One thread walks the steps and deals every step to the chains
-    // in turn, or (lane_threads) every chain gets a host thread of its own that walks all steps.
-    int run(int nsteps, int Bl, const std::function<int(int, int)> &step) {
-        int rc = 0, first = 0;
-        if (n > 1 && nsteps > 0 && h->lane_stagger) {
-            // step 0 of every chain by this thread: chain 0 records the start marks, chain k waits for its mark
-            for (int k = 1; k < n; ++k) marks.emplace_back(op_at((double)k / n, Bl), h->lane_sev[k - 1]);
-            for (int k = 0; k < n && !rc; ++k) {
-                t_lane = k;
-                if (k) BNDM_CHECK_HIP(hipStreamWaitEvent(stream(k), h->lane_sev[k - 1], 0));
-                rc = step(k, 0);
-            }
-            t_lane = 0;
-            if (rc) return rc;
-            first = 1;
-        }
-        if (n == 1 || !h->lane_threads) {
-            for (int s = first; s < nsteps && !rc; ++s)
-                for (int k = 0; k < n && !rc; ++k) {
-                    t_lane = k;
-                    rc = step(k, s);
-                }
-            t_lane = 0;
-            return rc;
-        }
-        int dev = 0;
-        BNDM_CHECK_HIP(hipGetDevice(&dev));
-        std::vector<int> rcs(n, 0);
-        std::vector<std::string> msgs(n);
-        auto chain = [&](int k) {
-            t_lane = k;
-            if (k && hipSetDevice(dev) != hipSuccess) {                 // (the current device is per thread)
-                rcs[k] = BNDM_E_NODEVICE;
-                msgs[k] = "lane thread: hipSetDevice failed";
-                return;
-            }
-            for (int s = first; s < nsteps && !rcs[k]; ++s) rcs[k] = step(k, s);
-            if (rcs[k]) msgs[k] = bndm_last_error();                    // the error text is per thread
-            t_lane = 0;
-        };
-        std::vector<std::thread> th;
-        for (int k = 1; k < n; ++k) th.emplace_back(chain, k);
-        chain(0);
-        for (std::thread &t : th) t.join();
-        for (int k = 0; k < n; ++k)
-            if (rcs[k]) {
-                set_error("%s", msgs[k].c_str());
-                return rcs[k];
-            }
-        return 0;
-    }
-    int close() {
-        if (n == 1) return 0;
-        for (size_t i = 0; i < h->lane_st.size(); ++i) {
-            BNDM_CHECK_HIP(hipEventRecord(h->lane_ev[1 + i], h->lane_st[i]));
-            BNDM_CHECK_HIP(hipStreamWaitEvent(st, h->lane_ev[1 + i], 0));
-        }
-        return 0;
-    }
-};
 
 }  // namespace
 
@@ -1828,15 +1691,6 @@ extern "C" void bndm_unet_destroy(bndm_unet *h) {
     if (h->t_pinned) (void)hipHostFree(h->t_pinned);
     if (h->t_uploaded) (void)hipEventDestroy(h->t_uploaded);
     for (void *p : h->retired) (void)hipFree(p);
-    for (hipStream_t s : h->lane_st)
-        if (s) {
-            (void)hipStreamSynchronize(s);
-            (void)hipStreamDestroy(s);
-        }
-    for (hipEvent_t e : h->lane_ev)
-        if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : h->lane_sev)
-        if (e) (void)hipEventDestroy(e);
     if (h->f32) f32_model_destroy(h->f32);
     for (Buf &b : h->bufs)
         if (b.ptr) (void)hipFree(b.ptr);
@@ -1865,21 +1719,6 @@ extern "C" int bndm_unet_load_param(bndm_unet *h, const char *name, const float 
                  (long long)ps.numel, (long long)numel);
     h->host[it->second].assign(host_data, host_data + numel);
     h->loaded[it->second] = 1;
-    return 0;
-}
-
-extern "C" int bndm_unet_set_lanes(bndm_unet *h, int lanes, int flags) {
-    BNDM_REQUIRE(h, "bndm_unet_set_lanes: NULL handle");
-    BNDM_REQUIRE(lanes >= 1 && lanes <= 4, "bndm_unet_set_lanes: %d lanes (1..4)", lanes);
-    BNDM_REQUIRE(h->kind == 0 && h->cfg.dtype != BNDM_DTYPE_F32, "bndm_unet_set_lanes: UNet handles in f16 / bf16 only");
-    if (h->finalized) {
-        set_error("bndm_unet_set_lanes: handle already finalised (the buffer copies are laid out by bndm_unet_finalize)");
-        return BNDM_E_STATE;
-    }
-    h->nlanes = lanes;
-    h->lane_threads = (flags & 1) != 0 && lanes > 1;
-    h->lane_cus = (flags & 2) != 0 && lanes > 1;
-    h->lane_stagger = (flags & 4) == 0;
     return 0;
 }
 
@@ -1932,25 +1771,7 @@ extern "C" int bndm_unet_finalize(bndm_unet *h) {
             for (Op &o : h->ops) o.dominant = o.kernel == "conv_t32<TH=8>";
     }
     for (Buf &bf : h->bufs) {
-        const size_t nb = h->nlanes > 1 ? bndm_unet::lane_stride(bf.bytes) * h->nlanes : bf.bytes;
-        BNDM_CHECK_HIP(hipMalloc(&bf.ptr, nb ? nb : 16));
-    }
-    if (h->nlanes > 1) {
-        h->lane_st.assign(h->lane_cus ? h->nlanes : h->nlanes - 1, nullptr);
-        h->lane_ev.assign(1 + h->lane_st.size(), nullptr);
-        if (h->lane_cus) {
-            const int per = 32 / h->nlanes;
-            for (int k = 0; k < h->nlanes; ++k) {
-                uint32_t words[8];                                      // 256 CUs
-                for (uint32_t &wd : words) wd = (uint32_t)(((1ull << per) - 1) << (k * per));
-                BNDM_CHECK_HIP(hipExtStreamCreateWithCUMask(&h->lane_st[k], 8, words));
-            }
-        } else {
-            for (hipStream_t &s : h->lane_st) BNDM_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        }
-        for (hipEvent_t &e : h->lane_ev) BNDM_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        h->lane_sev.assign(h->nlanes - 1, nullptr);
-        for (hipEvent_t &e : h->lane_sev) BNDM_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        BNDM_CHECK_HIP(hipMalloc(&bf.ptr, bf.bytes ? bf.bytes : 16));
     }
     for (auto &fn : b.post_alloc)
         if ((rc = fn())) return rc;
@@ -1982,37 +1803,22 @@ extern "C" int bndm_unet_sample_iadb(bndm_unet *h, float *x, const float *extra_
                  extra_in ? " (with conditioning)" : "");
     BNDM_REQUIRE(Cout == C || Cout == 2 * C, "bndm_unet_sample_iadb: out_channel %d for %d image channels", Cout, C);
     hipStream_t st = (hipStream_t)stream;
+    float *tbuf = (float *)h->P(h->s_t), *dbuf = (float *)h->P(h->s_d);
     const size_t img = (size_t)B * C * R * R;
+    int snap = 0;
     if (nb_step > 0 && !h->f32 && (rc = prepare_temb_table(h, nb_step, t_in, st))) return rc;
-    // chains: lane k owns samples [k * Bl, (k + 1) * Bl) and the k-th copy of every buffer slot; one chain (the whole batch on
-    // the caller's stream) unless bndm_unet_set_lanes asked for more and the batch divides
-    LaneFork lf;
-    if ((rc = lf.open(h, B, st))) return rc;
-    const int Bl = B / lf.n;
-    const size_t per = (size_t)C * R * R;                   // floats per sample of x (and of extra_in: Cin - C = C channels)
-    std::vector<int> snap_at(nb_step > 0 ? nb_step : 1, -1);           // snapshot index of step s, or -1
-    if (snap_mask && snapshots)
-        for (int s = 0, n = 0; s < nb_step; ++s)
-            if (snap_mask[s]) snap_at[s] = n++;
-    rc = lf.run(nb_step, Bl, [&](int k, int s) -> int {
-        hipStream_t sk = lf.stream(k);
-        float *xk = x + (size_t)k * Bl * per;
-        float *tbuf = (float *)h->P(h->s_t), *dbuf = (float *)h->P(h->s_d);
-        RunCtx r{Bl, sk, xk, extra_in ? extra_in + (size_t)k * Bl * per : nullptr, tbuf, dbuf};
-        r.chains = lf.n;
-        r.marks = lf.marks_for(k, s);
-        if (h->f32) hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(64), 0, sk, tbuf, t_in[s], Bl);
+    for (int s = 0; s < nb_step; ++s) {
+        RunCtx r{B, st, x, extra_in, tbuf, dbuf};
+        if (h->f32) hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(64), 0, st, tbuf, t_in[s], B);
         else r.tp_row = h->tp_table + (size_t)s * h->ntemb;
-        int e = run_forward(h, r);
-        if (e) return e;
-        if ((e = bndm_iadb_step(xk, dbuf, da[s], dg[s], Bl, C, Cout, R * R, sk))) return e;
-        if (snap_at[s] >= 0)
-            BNDM_CHECK_HIP(hipMemcpyAsync(snapshots + (size_t)snap_at[s] * img + (size_t)k * Bl * per, xk, (size_t)Bl * per * 4,
-                                          hipMemcpyDeviceToDevice, sk));
-        return 0;
-    });
-    const int rj = lf.close();                              // the caller's stream waits for every chain, also after an error
-    return rc ? rc : rj;
+        if ((rc = run_forward(h, r))) return rc;
+        if ((rc = bndm_iadb_step(x, dbuf, da[s], dg[s], B, C, Cout, R * R, stream))) return rc;
+        if (snap_mask && snapshots && snap_mask[s]) {
+            BNDM_CHECK_HIP(hipMemcpyAsync(snapshots + (size_t)snap * img, x, img * 4, hipMemcpyDeviceToDevice, st));
+            ++snap;
+        }
+    }
+    return 0;
 }
 
 extern "C" int bndm_unet_sample_ddim(bndm_unet *h, float *x, int B, int nb_step, const float *coef, float clip,
@@ -2023,30 +1829,22 @@ extern "C" int bndm_unet_sample_ddim(bndm_unet *h, float *x, int B, int nb_step,
     BNDM_REQUIRE(h->cfg.in_channels == h->cfg.out_channels, "bndm_unet_sample_ddim: eps-prediction needs Cin == Cout");
     hipStream_t st = (hipStream_t)stream;
     const int R = h->cfg.resolution;
+    float *tbuf = (float *)h->P(h->s_t), *dbuf = (float *)h->P(h->s_d);
+    const size_t n = (size_t)B * h->cfg.in_channels * R * R;
     if (nb_step > 0) {
         std::vector<float> ts(nb_step);
         for (int s = 0; s < nb_step; ++s) ts[s] = coef[5 * s];
         if (!h->f32 && (rc = prepare_temb_table(h, nb_step, ts.data(), st))) return rc;   // copied to pinned staging there
     }
-    LaneFork lf;                                             // chains as in bndm_unet_sample_iadb
-    if ((rc = lf.open(h, B, st))) return rc;
-    const int Bl = B / lf.n;
-    const size_t per = (size_t)h->cfg.in_channels * R * R;
-    rc = lf.run(nb_step, Bl, [&](int k, int s) -> int {
+    for (int s = 0; s < nb_step; ++s) {
         const float *c = coef + 5 * s;
-        hipStream_t sk = lf.stream(k);
-        float *xk = x + (size_t)k * Bl * per;
-        float *tbuf = (float *)h->P(h->s_t), *dbuf = (float *)h->P(h->s_d);
-        RunCtx r{Bl, sk, xk, nullptr, tbuf, dbuf};
-        r.chains = lf.n;
-        r.marks = lf.marks_for(k, s);
-        if (h->f32) hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(64), 0, sk, tbuf, c[0], Bl);
+        RunCtx r{B, st, x, nullptr, tbuf, dbuf};
+        if (h->f32) hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(64), 0, st, tbuf, c[0], B);
         else r.tp_row = h->tp_table + (size_t)s * h->ntemb;
-        const int e = run_forward(h, r);
-        return e ? e : bndm_ddim_step(xk, dbuf, c[1], c[2], c[3], c[4], clip, (size_t)Bl * per, sk);
-    });
-    const int rj = lf.close();
-    return rc ? rc : rj;
+        if ((rc = run_forward(h, r))) return rc;
+        if ((rc = bndm_ddim_step(x, dbuf, c[1], c[2], c[3], c[4], clip, n, stream))) return rc;
+    }
+    return 0;
 }
 
 extern "C" int bndm_unet_profile(bndm_unet *h, const float *sample, const float *timesteps, float *out, int B,

@@ -132,9 +132,7 @@ struct FusedArgs {
 // TH = 16 (256-pixel tiles) or 8 (128-pixel tiles); W must be a multiple of 16, H of TH
 // conv_t32 (unet_conv32.hip): 256-thread workgroups, two per CU, 32-channel K-steps, tile-contiguous weights
 bool conv_t32_supports(const FusedArgs &a);
-// chains: launches of this size in flight side by side on other streams (lanes) -- the one- / two-workgroups-per-CU
-// choice is made for their sum
-int launch_conv_t32(int dtype, int TH, const FusedArgs &a, hipStream_t st, int chains = 1);
+int launch_conv_t32(int dtype, int TH, const FusedArgs &a, hipStream_t st);
 int conv_t32_tiles_per_sample(int TH, int H, int W);
 // w_of(segment, out channel, channel within the segment, tap) -> fp32 weight; result is [n-tile][K-step][128][32]
 // rows: output channels per n-tile (128, or 32 for the head)

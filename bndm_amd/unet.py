@@ -119,7 +119,7 @@ class UNet2DModel(nn.Module):
                  up_block_types=("AttnUpBlock2D", "AttnUpBlock2D", "AttnUpBlock2D", "UpBlock2D"),
                  block_out_channels=(224, 448, 672, 896), layers_per_block=2, mid_block_scale_factor=1,
                  downsample_padding=1, act_fn="silu", attention_head_dim=8, norm_num_groups=32, norm_eps=1e-5,
-                 add_attention=True, dtype="f16", seed=None, lanes=1, lane_threads=False, lane_cus=False, lane_stagger=True, **unused):
+                 add_attention=True, dtype="f16", seed=None, **unused):
         super().__init__()
         if act_fn != "silu":
             raise NotImplementedError(f"act_fn={act_fn!r}: the HIP path implements SiLU (every shipped script)")
@@ -138,12 +138,6 @@ class UNet2DModel(nn.Module):
                            block_out_channels=boc, layers_per_block=layers_per_block, act_fn=act_fn,
                            attention_head_dim=8, norm_num_groups=32, norm_eps=1e-5, add_attention=True)
         self.compute_dtype = dtype
-        # sampling loops as `lanes` chains of launches on separate HIP streams inside the engine (bndm_unet_set_lanes:
-        # the in-GPU analogue of DataParallel's batch split, iadb_bn.py:716); results are bit-identical for any value
-        self.lanes = int(lanes)
-        self.lane_threads = bool(lane_threads)           # one host thread per chain instead of one for all
-        self.lane_cus = bool(lane_cus)                   # every chain on its own share of the CUs (CU-masked streams)
-        self.lane_stagger = bool(lane_stagger)           # chain k starts k / lanes of a forward behind chain 0
         temb = boc[0] * 4
         self.conv_in = _conv(in_channels, boc[0], 3)
         self.time_embedding = _TimeEmbedding(boc[0], temb)
@@ -198,7 +192,7 @@ class UNet2DModel(nn.Module):
             pass
 
     def _ensure_engine(self, B, res, device):
-        key = (self._param_version(), res, self.compute_dtype, device.index, self.lanes, self.lane_threads, self.lane_cus, self.lane_stagger)
+        key = (self._param_version(), res, self.compute_dtype, device.index)
         if self._engine is not None and self._engine_key is not None and self._engine_key[0] == key \
                 and self._engine_key[1] >= B:
             return self._engine
@@ -239,8 +233,6 @@ class UNet2DModel(nn.Module):
                 extra = set(sd) - seen
                 if extra:
                     raise KeyError(f"unexpected keys in state dict: {sorted(extra)[:4]}...")
-                if self.lanes > 1 and self.compute_dtype not in ("f32", "fp32"):
-                    _lib.check(lib.bndm_unet_set_lanes(h, self.lanes, int(self.lane_threads) | 2 * int(self.lane_cus) | 4 * int(not self.lane_stagger)), "bndm_unet_set_lanes")
                 _lib.check(lib.bndm_unet_finalize(h), "bndm_unet_finalize")
             except Exception:
                 lib.bndm_unet_destroy(h)

@@ -132,19 +132,6 @@ int  bndm_unet_param_info(const bndm_unet *h, int index, char *name, size_t name
 /* model.load_state_dict(...) (iadb_bn.py:714): one tensor, host f32, PyTorch layout
  * (conv OIHW, linear [out,in]); converted/re-laid out on upload. */
 int  bndm_unet_load_param(bndm_unet *h, const char *name, const float *host_data, int64_t numel);
-/* Sampling loops as `lanes` (1..4, default 1) independent chains of launches on separate HIP streams: the batch of
- * bndm_unet_sample_iadb / _ddim is cut into `lanes` contiguous parts that share the weights, own a copy of every
- * activation buffer (sized for max_batch each) and are enqueued side by side, so that one chain's kernel boundaries,
- * prologues and epilogues are another chain's MFMA time.  Samples are independent (GroupNorm / attention are per
- * sample), so results are bit-identical to one lane; to the caller the loop stays one in-order piece of work on `stream`.
- * Applies when B is a multiple of `lanes`, else the loop runs as one chain.  Before bndm_unet_finalize only.
- * flags: bit 0 -- one host thread per chain for the duration of a sampling call instead of the calling thread dealing
- * every step to the chains in turn (more launches per second when the host is the limit); bit 1 -- every chain on a
- * stream with its own CU mask (an equal, disjoint share of the CUs of every XCD) instead of sharing all CUs; bit 2 --
- * no start offsets (by default chain k starts when chain 0 is k / lanes of the way through its first forward, so that
- * the chains do not run the same kernel at the same time).
- * The reference's counterpart is torch.nn.DataParallel's batch split (iadb_bn.py:716), here inside one GPU. */
-int  bndm_unet_set_lanes(bndm_unet *h, int lanes, int flags);
 /* all parameters present -> pack derived tables; must precede forward */
 int  bndm_unet_finalize(bndm_unet *h);
 

@@ -41,16 +41,3 @@ def test_overlap_tool_on_a_synthetic_trace(tmp_path):
     assert lines["conv_s"][1] == "1"
     two = [ln for ln in out.splitlines() if ln.startswith("distinct queues")][0]
     assert "2:  57.1%" in two                                                    # 80 us of 140
-
-
-def test_lanes_options_reach_the_model_and_the_cli():
-    """lanes are host-side plumbing down to bndm_unet_set_lanes (include/bndm_hip.h); no GPU needed to build the module"""
-    sys.path.insert(0, ROOT)
-    from bndm_amd.sampler import get_model
-    from bndm_amd import _lib, cli_iadb
-    m = get_model(3, 6, 64, lanes=4, lane_cus=True, lane_threads=True, lane_stagger=False)
-    assert (m.lanes, m.lane_cus, m.lane_threads, m.lane_stagger) == (4, True, True, False)
-    assert get_model(3, 6, 64).lanes == 1                                   # default: one chain
-    assert _lib.SIGNATURES["bndm_unet_set_lanes"][1] == [_lib._vp, _lib._i, _lib._i]
-    src = open(os.path.join(ROOT, "bndm_amd", "cli_iadb.py")).read()
-    assert "--lanes" in src and "--lane_cus" in src

@@ -107,8 +107,15 @@ def main():
             cur.wait_stream(s)
         return torch.cat(out, 0)
 
-    eng = get_model(3, 6, R, dtype="f16", seed=0, lanes=NL, lane_cus=a.cumask, lane_stagger=not a.no_stagger).to(dev).eval()      # the product form: chains inside the engine
-    engt = get_model(3, 6, R, dtype="f16", seed=0, lanes=NL, lane_threads=True, lane_cus=a.cumask, lane_stagger=not a.no_stagger).to(dev).eval()   # ... one host thread per chain
+    # the in-engine forms exist only in a library built with tools/experiments/lanes.patch (bndm_unet_set_lanes); the product
+    # library runs the first two forms, which need no library change, and those decide whether the patch is worth applying
+    have_lanes = "bndm_unet_set_lanes" in _lib.SIGNATURES
+    if not have_lanes:
+        print("(library without bndm_unet_set_lanes: one stream vs engine handle + host thread per chain only)")
+    eng = engt = None
+    if have_lanes:
+        eng = get_model(3, 6, R, dtype="f16", seed=0, lanes=NL, lane_cus=a.cumask, lane_stagger=not a.no_stagger).to(dev).eval()      # chains inside the engine
+        engt = get_model(3, 6, R, dtype="f16", seed=0, lanes=NL, lane_threads=True, lane_cus=a.cumask, lane_stagger=not a.no_stagger).to(dev).eval()   # ... one host thread per chain
 
     def in_engine():
         return sample_iadb(eng, x0, N, "sigmoid", params, 6, "gaussianBN", "train")
@@ -132,17 +139,26 @@ def main():
         ka = [k for k, _, _ in engine_ops(full._ensure_engine(B, R, dev))]
         kb = [k for k, _, _ in engine_ops(lanes[0]._ensure_engine(hb, R, dev))]
         print("   launch lists differ at ops:", [i for i, (p, q) in enumerate(zip(ka, kb)) if p != q][:20])
-    yc, _ = timed(in_engine)
-    same_c = bool(torch.equal(ya, yc))
-    yd, _ = timed(in_engine_threads)
-    same_d = bool(torch.equal(ya, yd))
+    same_c = same_d = None
+    if have_lanes:
+        yc, _ = timed(in_engine)
+        same_c = bool(torch.equal(ya, yc))
+        yd, _ = timed(in_engine_threads)
+        same_d = bool(torch.equal(ya, yd))
     ta, tb, tc, td = [], [], [], []
     for _ in range(a.passes):
         ta.append(timed(one_stream)[1])
         tb.append(timed(multi_stream)[1])
-        tc.append(timed(in_engine)[1])
-        td.append(timed(in_engine_threads)[1])
-    fa, fb, fc, fd = B / min(ta), B / min(tb), B / min(tc), B / min(td)
+        if have_lanes:
+            tc.append(timed(in_engine)[1])
+            td.append(timed(in_engine_threads)[1])
+    fa, fb = B / min(ta), B / min(tb)
+    if not have_lanes:
+        print(f"one stream  B={B}: {fa:8.2f} images/s   ({min(ta) / N * 1e3:.3f} ms per step)   all: {[round(B / t, 1) for t in ta]}")
+        print(f"{NL} streams B={hb}x{NL}: {fb:8.2f} images/s   ({min(tb) / N * 1e3:.3f} ms per step)   all: {[round(B / t, 1) for t in tb]}")
+        print(f"ratio: engine handle + python thread per chain {fb / fa:.3f} (bit-identical: {same})")
+        return
+    fc, fd = B / min(tc), B / min(td)
     print(f"one stream  B={B}: {fa:8.2f} images/s   ({min(ta) / N * 1e3:.3f} ms per step)   all: {[round(B / t, 1) for t in ta]}")
     print(f"{NL} streams B={hb}x{NL}: {fb:8.2f} images/s   ({min(tb) / N * 1e3:.3f} ms per step)   all: {[round(B / t, 1) for t in tb]}")
     print(f"in-engine lanes={NL}: {fc:8.2f} images/s   ({min(tc) / N * 1e3:.3f} ms per step)   all: {[round(B / t, 1) for t in tc]}")
