@@ -1054,6 +1054,7 @@ bool conv_t32_supports(const FusedArgs &a) {
     for (int i = 0; i < a.nseg; ++i) {
         if (a.seg[i].C % 32 || a.seg[i].C > 2047) return false;
         if (a.seg[i].up != a.seg[0].up) return false;      // the piece descriptors carry the source resolution
+        if (a.seg[i].taps == 1 && a.seg[i].ss_off >= 0) return false;   // 1x1 chunks are read raw: no normalised 1x1 segment
         if (a.seg[i].taps == 1) seen1 = true;
         else if (seen1) return false;
         else if ((a.seg[i].ss_off >= 0) != (a.seg[0].ss_off >= 0)) return false;   // all 3x3 segments normalised, or none

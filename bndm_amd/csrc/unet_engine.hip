@@ -590,7 +590,7 @@ struct Builder {
             const std::vector<float> wp = pack_weights_t32(a.seg, a.nseg, out.C, [&](int si, int co, int c, int t) {
                 const WSeg &w = ws[si];
                 const float v = (*w.w)[((size_t)co * w.cin_total + w.c_begin + c) * w.taps + t];
-                return a.seg[si].ss_off >= 0 ? 0.6931471805599453f * v : v;
+                return a.seg[si].taps == 9 && a.seg[si].ss_off >= 0 ? 0.6931471805599453f * v : v;   // (1x1 chunks are read raw)
             }, head ? 32 : 128);
             if ((rc = upload_16(h, wp, &Wp))) return;
         }

@@ -19,7 +19,10 @@ from tests.hipmock import harness as H  # noqa: E402
 
 def main():
     lib = os.path.abspath(sys.argv[1]) if len(sys.argv) > 1 else H.PRODUCT_LIB
-    out = {"library_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "scenarios": {}}
+    from tests.hipmock.kernargs import code_objects
+    out = {"library_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(),
+           # one hash per .hip source: the gfx950 code objects the validated build ran
+           "device_code_sha256": [hashlib.sha256(co).hexdigest() for co in code_objects(lib)], "scenarios": {}}
     with tempfile.TemporaryDirectory() as td:
         for s in H.SCENARIOS:
             lines = H.run_scenario(lib, s, td)

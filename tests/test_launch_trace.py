@@ -69,3 +69,13 @@ def test_launch_list_of_the_headline_workload(workdir):
     # the whole call) + the Euler update
     assert len(ln) == 3 * 94 + 2 and [d["name"] for d in ln].count("iadb_step_kernel") == 3
     assert sum(1 for x in loop if x.startswith("memcpy_async") and "src=0x" in x) == 2
+
+
+def test_device_code_is_the_gpu_validated_build(gold):
+    """the gfx950 code objects inside the library are byte for byte those of the build the GPU suite passed on: together
+    with the identical host trace above, a rebuilt library behaves exactly like the validated one"""
+    import hashlib
+    from tests.hipmock.kernargs import code_objects
+    got = [hashlib.sha256(co).hexdigest() for co in code_objects(H.PRODUCT_LIB)]
+    assert got == gold["device_code_sha256"], "device code differs from the GPU-validated build: run the GPU suite, then " \
+                                              "tests/golden/make_launch_traces.py"

@@ -11,3 +11,4 @@ hipcc -O3 --offload-arch=gfx950 -w coldload.hip -o coldload.bin
 hipcc -O3 --offload-arch=gfx950 -std=c++17 -w t32_bench.cpp -o t32_bench.bin -L../../bndm_amd -lbndm_hip -Wl,-rpath,'$ORIGIN/../../bndm_amd'
 hipcc -O3 --offload-arch=gfx950 -w anyorder.hip -o anyorder.bin
 hipcc -O3 --offload-arch=gfx950 -w flagwait.hip -o flagwait.bin
+hipcc -O3 --offload-arch=gfx950 -w cumask_probe.hip -o cumask_probe.bin
