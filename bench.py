@@ -459,7 +459,11 @@ def main():
         del wl, model
         torch.cuda.empty_cache()
         for oc in ("c3", "c4", "c5"):
-            others[oc] = short_pass(oc, args.dtype, dev, lib)
+            # a failure in a side configuration must not cost the headline line (the timed region is over)
+            try:
+                others[oc] = short_pass(oc, args.dtype, dev, lib)
+            except Exception as e:                                   # noqa: BLE001 -- reported, not swallowed
+                others[oc] = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.empty_cache()
         wl = None
 
@@ -467,7 +471,10 @@ def main():
         imgs = args.gpus * B * args.steps
         base = None
         if not (args.no_cpu_baseline or args.gpus > 1 or args.profile_only):
-            base = cpu_baseline()
+            try:
+                base = cpu_baseline()
+            except Exception as e:                                   # noqa: BLE001
+                base = {"error": f"{type(e).__name__}: {e}"[:300]}
         line = {
             "metric": metric_name,
             "value": round(imgs / elapsed, 3), "unit": "images/sec", "n_gpus": args.gpus, "steps": args.steps,

@@ -1,0 +1,59 @@
+"""CPU checks of candidate libraries' HOST side under the recording HIP runtime (tests/hipmock); not collected by `pytest`
+(pytest.ini), run by name:  python -m pytest tools/experiments/extra_tests/test_candidate_hosts.py -q"""
+import json
+import os
+import struct
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, ROOT)
+from tests.hipmock import harness as H  # noqa: E402
+
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "launch_traces.json")))
+
+
+def lib(name):
+    p = os.path.join(ROOT, "tools", name)
+    if not os.path.exists(p):
+        pytest.skip(f"tools/{name} not built (tools/build_candidates.sh)")
+    return p
+
+
+@pytest.mark.parametrize("name", ["lib_v9.so", "lib_v12.so", "lib_v13.so"])
+@pytest.mark.parametrize("scenario", ["c2", "c4"])
+def test_kernel_only_candidates_keep_the_host_side(name, scenario, tmp_path):
+    """staged 1x1 chunks / scalar chunk descriptors / first-round write-back change device code only: same launches, same
+    argument bytes, same uploads as the product (LDS sizes may differ: they are part of the kernel)"""
+    got = H.digest(H.run_scenario(lib(name), scenario, str(tmp_path)))
+    want = GOLD["scenarios"][scenario]
+    strip = lambda recs: [[" ".join(x.split(" ")[:3]) for x in r["launches"]] for r in recs]      # name, grid, block
+    assert strip(got) == strip(want)
+    assert [r["calls"] for r in got] == [r["calls"] for r in want]
+
+
+@pytest.mark.parametrize("scenario,flags,cout", [("c2", 7, 6), ("c5", 7, 8), ("cond", 3, 3)])
+def test_euler_step_in_the_head_launch(scenario, flags, cout, tmp_path):
+    """lib_v15: no iadb_step launch in the in-engine loop; the head launch carries x, da, dg and the flag bits
+    (FusedArgs offsets: temb_bstride 152, temb_off 156, resid 160, out_nchw32 176, Cout 204); forwards outside the loop unchanged"""
+    lines = H.run_scenario(lib("lib_v15.so"), scenario, str(tmp_path))
+    H.check_pointers(lines)
+    for mark, body in H.stages(lines):
+        ls = [H.parse_launch(x) for x in body if x.startswith("launch ")]
+        heads = [d for d in ls if d["name"] == "conv_t32" and "Li32ELi0E" in d["sym"]]
+        if mark.startswith("sample_iadb"):
+            x = int([ln for ln in body if ln.startswith("malloc")][0].split()[1], 16)
+            assert not [d for d in ls if d["name"] == "iadb_step_kernel"]
+            steps = 3 if "steps=3" in mark else 2
+            assert len(heads) == steps
+            for s, d in enumerate(heads):
+                a = d["args"][0]
+                da, dg = struct.unpack_from("<ff", a, 152)
+                resid, = struct.unpack_from("<Q", a, 160)
+                fl, = struct.unpack_from("<i", a, 176)
+                co, = struct.unpack_from("<i", a, 204)
+                assert resid == x and fl == flags and co == cout
+                assert da == struct.unpack("<f", struct.pack("<f", -1.0 / steps))[0] and dg == struct.unpack("<f", struct.pack("<f", -0.5 / steps))[0]
+        elif mark.startswith("forward"):
+            assert len(heads) == 1 and struct.unpack_from("<i", heads[0]["args"][0], 176)[0] == 1

@@ -9,5 +9,9 @@ echo "== A/B, two interleaved rounds: shipped | v9 staged 1x1 chunks | v12 scala
 timeout 1500 python tools/ab_libs.py --rounds 2 --acc bndm_amd/libbndm_hip.so tools/lib_v9.so tools/lib_v12.so tools/lib_v13.so 2>&1 | tail -16
 echo "== v8 (round-4 patch: pair-granular sums, sums-first prologue; conv_t32<TH=32> only with BNDM_TH32_MIN): accuracy + A/B"
 timeout 1200 python tools/ab_libs.py --rounds 2 --acc bndm_amd/libbndm_hip.so tools/lib_v8.so "tools/lib_v8.so@BNDM_TH32_MIN=256" 2>&1 | tail -12
+echo "== v15 (Euler update in the head launch): the loop tests of tests/ on the candidate, then a timed A/B of the whole loop"
+mkdir -p /tmp/v15 && cp -r bndm_amd tests oracle include bluenoise utils.py iadb_bn.py ddim_diffusers.py latent_iadb_bn_diffusers.py input_args.py pytest.ini __graft_entry__.py bench.py /tmp/v15/ 2>/dev/null && cp tools/lib_v15.so /tmp/v15/bndm_amd/libbndm_hip.so
+(cd /tmp/v15 && timeout 900 python -m pytest tests/test_gpu_steps.py tests/test_gpu_tail.py tests/test_gpu_benched.py tests/test_gpu_cli.py -m gpu -q -x 2>&1 | tail -4)
+timeout 900 python tools/ab_libs.py --rounds 2 --full bndm_amd/libbndm_hip.so tools/lib_v15.so 2>&1 | tail -8
 echo "== first-level widths 64 / 256 (parked test; on the shipped library)"
 timeout 600 python -m pytest tools/experiments/extra_tests/test_gpu_first_level_widths.py -m gpu -q 2>&1 | tail -4
