@@ -13,5 +13,12 @@ echo "== v15 (Euler update in the head launch): the loop tests of tests/ on the 
 mkdir -p /tmp/v15 && cp -r bndm_amd tests oracle include bluenoise utils.py iadb_bn.py ddim_diffusers.py latent_iadb_bn_diffusers.py input_args.py pytest.ini __graft_entry__.py bench.py /tmp/v15/ 2>/dev/null && cp tools/lib_v15.so /tmp/v15/bndm_amd/libbndm_hip.so
 (cd /tmp/v15 && timeout 900 python -m pytest tests/test_gpu_steps.py tests/test_gpu_tail.py tests/test_gpu_benched.py tests/test_gpu_cli.py -m gpu -q -x 2>&1 | tail -4)
 timeout 900 python tools/ab_libs.py --rounds 2 --full bndm_amd/libbndm_hip.so tools/lib_v15.so 2>&1 | tail -8
+echo "== c5 (latent UNet, B = 8 per GPU) under the EXISTING switches: is a batch-size heuristic between tested code paths worth anything?"
+for e in "" "BNDM_NO_TAIL=1" "BNDM_TH16_MIN=1"; do
+  echo -n "-- c5 ${e:-default}:  "
+  env $e timeout 600 python bench.py --config c5 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}; print(d['value'], 'images/s;', r.get('ms_per_forward_total'), 'ms per forward,', r.get('launches_total'), 'launches')"
+done
 echo "== first-level widths 64 / 256 (parked test; on the shipped library)"
 timeout 600 python -m pytest tools/experiments/extra_tests/test_gpu_first_level_widths.py -m gpu -q 2>&1 | tail -4
