@@ -46,6 +46,20 @@ def run_scenario(lib, name, outdir, lanes=1, flags=0):
     return [_mask_padding(ln) for ln in open(trace).read().splitlines()]
 
 
+def run_script(script, lib, outdir, *args):
+    """runs tests/hipmock/<script> <lib> <args> under the stand-in -> its stdout"""
+    mock = build_mock(outdir)
+    trace = os.path.join(outdir, f"trace_{script}_{os.path.basename(lib)}.txt")
+    if os.path.exists(trace):
+        os.remove(trace)
+    env = dict(os.environ, LD_LIBRARY_PATH=mock + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""), HIPMOCK_TRACE=trace,
+               HIPMOCK_KERNARGS=kernargs_file(lib, outdir))
+    r = subprocess.run([sys.executable, os.path.join(HERE, script), lib, *map(str, args)], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, f"{script} failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+    return r.stdout
+
+
 def _mask_padding(ln):
     """struct padding passed by value is whatever the host stack held: ZSrc (bluenoise.hip: pointer + 3 ints = 20 of 24 bytes)"""
     if ln.startswith("launch ") and "4ZSrcE" in ln:

@@ -79,3 +79,12 @@ def test_device_code_is_the_gpu_validated_build(gold):
     got = [hashlib.sha256(co).hexdigest() for co in code_objects(H.PRODUCT_LIB)]
     assert got == gold["device_code_sha256"], "device code differs from the GPU-validated build: run the GPU suite, then " \
                                               "tests/golden/make_launch_traces.py"
+
+
+def test_conv_t32_launches_compute_their_layers(workdir):
+    """Every conv_t32 launch of a forward, evaluated on the CPU from its kernel arguments and uploaded tables (packed weights
+    decoded, GroupNorm finalised from the partial sums, segments in order), equals the layer's definition on the ORIGINAL state-dict
+    tensors: weight packing, K-step order, ln 2 fold, concat / upsample / shortcut segments, gamma / beta / bias wiring.  Host
+    side of the dominant kernel only -- nothing here runs device code (tests/hipmock/check_conv_t32.py)."""
+    out = H.run_script("check_conv_t32.py", H.PRODUCT_LIB, workdir)
+    assert "OK 34 conv_t32 launches" in out, out[-2000:]
