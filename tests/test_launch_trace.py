@@ -88,3 +88,12 @@ def test_conv_t32_launches_compute_their_layers(workdir):
     side of the dominant kernel only -- nothing here runs device code (tests/hipmock/check_conv_t32.py)."""
     out = H.run_script("check_conv_t32.py", H.PRODUCT_LIB, workdir)
     assert "OK 34 conv_t32 launches" in out, out[-2000:]
+
+
+def test_conv_s_launches_compute_their_layers(workdir):
+    """The same for the <= 8x8 levels (tests/hipmock/check_conv_s.py): every conv_s launch evaluated from its step lists, round
+    table, weight stream and epilogue requests equals the module's definition -- 3x3 / stride-2 / nearest-2x / 1x1 shortcut
+    convolutions, q|k|v + softmax, to_out, and the GroupNorm(+SiLU) copies, whose consumers are found by value in the state
+    dict and must have the requested group size."""
+    out = H.run_script("check_conv_s.py", H.PRODUCT_LIB, workdir)
+    assert "OK 51 conv_s launches" in out, out[-2000:]
