@@ -1,0 +1,446 @@
+"""TEST INFRASTRUCTURE: one whole UNet forward executed on the CPU THROUGH THE ENGINE'S OWN LAUNCH LIST.
+
+Under the recording HIP runtime (tests/hipmock) the library's bndm_unet_forward leaves a trace of every launch with its
+argument bytes, and its uploads sit in readable "device" memory.  This script replays that trace: each launch is handed to
+a numpy model of its kernel's CONTRACT -- what the kernel reads (sources, packed weights, step lists, partial sums, rows),
+what it writes (activations, GroupNorm partial sums and normalised copies, split-K slabs, the fp32 output) and the arithmetic
+in between, with the 16-bit roundings where the kernel rounds -- and the models read and write the same buffers the real
+kernels would.  The final fp32 output is saved; tests/test_launch_trace.py compares it with oracle/unet_oracle.py on the same
+weights and inputs.
+
+What agreement means: the launch list, its order, every buffer hand-over between launches (skip connections, concatenations,
+normalised copies, partial sums, split-K slabs, the time-embedding table), every packed weight / table layout and every
+per-launch parameter are right for a forward at batch 2 -- the whole HOST side of the engine.  The kernels' device code is not
+involved at any point.
+
+    LD_LIBRARY_PATH=<stand-in dir> HIPMOCK_TRACE=t.txt HIPMOCK_KERNARGS=ka.txt python tests/hipmock/exec_forward.py lib.so out_dir
+"""
+import ctypes as C
+import json
+import os
+import re
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from bndm_amd import _lib  # noqa: E402
+from tests.hipmock import drive, harness as H  # noqa: E402
+from tests.hipmock.check_conv_s import Round, TailArgs  # noqa: E402
+from tests.hipmock.check_conv_t32 import LOG2E, FusedArgs, conv3x3, decode_weights, dev, silu, up2  # noqa: E402
+
+f16 = np.float16
+
+
+def r16(x):
+    return x.astype(f16).astype(np.float32)
+
+
+class CSeg(C.Structure):
+    _fields_ = [("src", C.c_uint64), ("C", C.c_int), ("taps", C.c_int), ("up", C.c_int), ("pad", C.c_int)]
+
+
+class ConvArgs(C.Structure):                       # csrc/unet_kernels.hpp: struct ConvArgs
+    _fields_ = [("seg", CSeg * 4), ("nseg", C.c_int), ("Wgt", C.c_uint64), ("bias", C.c_uint64), ("temb", C.c_uint64),
+                ("temb_bstride", C.c_int), ("temb_off", C.c_int), ("resid", C.c_uint64), ("out", C.c_uint64), ("B", C.c_int),
+                ("H", C.c_int), ("W", C.c_int), ("stride", C.c_int), ("Cout", C.c_int), ("Ktot", C.c_int), ("splitk", C.c_int),
+                ("zeros", C.c_uint64), ("steps", C.c_uint64), ("counters", C.c_uint64), ("wtiled", C.c_int), ("wmajor", C.c_int)]
+
+
+class SlabSrc(C.Structure):                        # struct GnSlabSrc
+    _fields_ = [("part", C.c_uint64), ("splitk", C.c_int), ("bias", C.c_uint64), ("temb", C.c_uint64), ("temb_bstride", C.c_int),
+                ("temb_off", C.c_int), ("resid", C.c_uint64), ("raw_out", C.c_uint64)]
+
+
+assert C.sizeof(ConvArgs) == 216
+
+
+def u64(b):
+    return int.from_bytes(b, "little")
+
+
+def i32(b):
+    return int.from_bytes(b, "little", signed=True)
+
+
+def f32(b):
+    return float(np.frombuffer(b, np.float32)[0])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def k_temb_mlp(L):
+    t, C0, D, W1t, b1, W2t, b2, act = [L["args"][i] for i in range(8)]
+    t, C0, D, W1t, b1, W2t, b2, act = u64(t), i32(C0), i32(D), u64(W1t), u64(b1), u64(W2t), u64(b2), u64(act)
+    B = int(L["g"].split(",")[1])
+    tv = dev(t, np.float32, B).astype(np.float64)
+    half = C0 // 2
+    f = np.exp(-9.210340371976184 * np.arange(half) / half)
+    ang = tv[:, None] * f[None]
+    emb = np.concatenate([np.cos(ang), np.sin(ang)], 1).astype(np.float32)            # flip_sin_to_cos
+    h1 = silu(emb @ dev(W1t, np.float32, C0 * D).reshape(C0, D) + dev(b1, np.float32, D))
+    v = h1 @ dev(W2t, np.float32, D * D).reshape(D, D) + dev(b2, np.float32, D)
+    dev(act, f16, B * D)[:] = silu(v).astype(f16).ravel()
+
+
+def igemm_weights(a):
+    rows = -(-a.Cout // 128) * 128 if a.wtiled else None
+    if a.wtiled:
+        ks = a.Ktot // 64
+        wt = dev(a.Wgt, f16, rows * a.Ktot).astype(np.float32).reshape(rows // 128, ks, 128, 8, 8)
+        wp = np.zeros((rows, a.Ktot), np.float32)
+        r = np.arange(128)
+        for j in range(8):
+            g = j ^ ((r >> 1) & 7)                                                    # slot j of row r holds k-group g
+            for nt in range(rows // 128):
+                for s in range(ks):
+                    for rr in range(128):
+                        wp[nt * 128 + rr, s * 64 + g[rr] * 8:s * 64 + g[rr] * 8 + 8] = wt[nt, s, rr, j]
+        return wp[:a.Cout]
+    # plain [Cout_pad][Ktot]: the row padding is unknown here, but only the first Cout rows matter
+    return dev(a.Wgt, f16, a.Cout * a.Ktot).astype(np.float32).reshape(a.Cout, a.Ktot)
+
+
+def k_igemm(L):
+    a = ConvArgs.from_buffer_copy(L["args"][0])
+    epi = int(re.search(r"conv_igemmI\w+?_?Li\d+ELi\d+ELi\d+ELi\d+ELi(\d+)E", L["sym"]).group(1))
+    Wm = igemm_weights(a)                                                             # [Cout][Ktot], k: segment -> tap -> channel
+    B, Hh, Ww = a.B, a.H, a.W
+    M = B * Hh * Ww
+    acc = np.zeros((M, a.Cout), np.float32)
+    koff = 0
+    for i in range(a.nseg):
+        s = a.seg[i]
+        if a.stride == 2:
+            hs, ws = 2 * Hh, 2 * Ww
+        elif s.up:
+            hs, ws = Hh // 2, Ww // 2
+        else:
+            hs, ws = Hh, Ww
+        x = dev(s.src, f16, B * hs * ws * s.C).astype(np.float32).reshape(B, hs, ws, s.C)
+        Wseg = Wm[:, koff:koff + s.taps * s.C].reshape(a.Cout, s.taps, s.C)
+        for b in range(B):
+            xb = up2(x[b]) if s.up else x[b]
+            if s.taps == 9:
+                w4 = Wseg.transpose(0, 2, 1).reshape(a.Cout, s.C, 3, 3)
+                full = conv3x3(xb, w4)
+                if a.stride == 2:
+                    full = full[0::2, 0::2]
+                acc[b * Hh * Ww:(b + 1) * Hh * Ww] += full.reshape(Hh * Ww, -1)
+            else:
+                assert a.stride == 1
+                acc[b * Hh * Ww:(b + 1) * Hh * Ww] += xb.reshape(Hh * Ww, s.C) @ Wseg[:, 0].T
+        koff += s.taps * s.C
+    if a.splitk > 1:                                       # fp32 slabs [splitk][M][Cout], no bias: the whole sum in slab 0
+        slabs = dev(a.out, np.float32, a.splitk * M * a.Cout).reshape(a.splitk, M, a.Cout)
+        slabs[:] = 0
+        slabs[0] = acc
+        return
+    if a.bias:
+        acc += dev(a.bias, np.float32, a.Cout)
+    if a.temb:
+        for b in range(B):
+            acc[b * Hh * Ww:(b + 1) * Hh * Ww] += dev(a.temb + 4 * (b * a.temb_bstride + a.temb_off), np.float32, a.Cout)
+    if epi == 1:                                           # EPI_F32_ROWS
+        assert not a.resid
+        dev(a.out, np.float32, M * a.Cout)[:] = acc.ravel()
+        return
+    assert epi == 0
+    if a.resid:
+        acc += dev(a.resid, f16, M * a.Cout).astype(np.float32).reshape(M, a.Cout)
+    dev(a.out, f16, M * a.Cout)[:] = acc.astype(f16).ravel()
+
+
+def k_splitk_reduce(L):
+    part, splitk = u64(L["args"][0]), i32(L["args"][1])
+    a = ConvArgs.from_buffer_copy(L["args"][2])
+    logHW = i32(L["args"][3])
+    M = a.B << logHW
+    s = dev(part, np.float32, splitk * M * a.Cout).reshape(splitk, M, a.Cout).sum(0)
+    if a.bias:
+        s = s + dev(a.bias, np.float32, a.Cout)
+    if a.temb:
+        for b in range(a.B):
+            s[b << logHW:(b + 1) << logHW] += dev(a.temb + 4 * (b * a.temb_bstride + a.temb_off), np.float32, a.Cout)
+    if a.resid:
+        s = s + dev(a.resid, f16, M * a.Cout).astype(np.float32).reshape(M, a.Cout)
+    dev(a.out, f16, M * a.Cout)[:] = s.astype(f16).ravel()
+
+
+def k_conv_in(L):
+    A = L["args"]
+    x, Cx, extra, Ce, W16, bias, out, stats, B, logH, logW, C0, KP = (u64(A[0]), i32(A[1]), u64(A[2]), i32(A[3]), u64(A[4]), u64(A[5]),
+                                                                         u64(A[6]), u64(A[7]), i32(A[8]), i32(A[9]), i32(A[10]), i32(A[11]), i32(A[12]))
+    Hh, Ww = 1 << logH, 1 << logW
+    xin = dev(x, np.float32, B * Cx * Hh * Ww).reshape(B, Cx, Hh, Ww)
+    if Ce:
+        xin = np.concatenate([xin, dev(extra, np.float32, B * Ce * Hh * Ww).reshape(B, Ce, Hh, Ww)], 1)
+    Cin = Cx + Ce
+    W = dev(W16, f16, C0 * KP).astype(np.float32).reshape(C0, KP)[:, :9 * Cin].reshape(C0, Cin, 3, 3)   # k = ci * 9 + ky * 3 + kx
+    o = dev(out, f16, B * Hh * Ww * C0).reshape(B, Hh * Ww, C0)
+    for b in range(B):
+        y = conv3x3(r16(xin[b].transpose(1, 2, 0)), W) + dev(bias, np.float32, C0)
+        o[b] = y.reshape(Hh * Ww, C0).astype(f16)
+    if stats:
+        ns = (Hh * Ww) >> 7
+        st = dev(stats, np.float32, B * ns * C0 * 2).reshape(B, ns, C0, 2)
+        v = o.astype(np.float32).reshape(B, ns, 128, C0)
+        st[..., 0] = v.sum(2)
+        st[..., 1] = (v.astype(np.float64) ** 2).sum(2)
+
+
+def k_gn_stats(L):
+    A = L["args"]
+    x1, C1, x2, C2, HW, partial, nslab = u64(A[0]), i32(A[1]), u64(A[2]), i32(A[3]), i32(A[4]), u64(A[5]), i32(A[6])
+    B = int(L["g"].split(",")[1])
+    x = dev(x1, f16, B * HW * C1).astype(np.float32).reshape(B, HW, C1)
+    if C2:
+        x = np.concatenate([x, dev(x2, f16, B * HW * C2).astype(np.float32).reshape(B, HW, C2)], -1)
+    Cc = C1 + C2
+    st = dev(partial, np.float32, B * nslab * Cc * 2).reshape(B, nslab, Cc, 2)
+    v = x.reshape(B, nslab, HW // nslab, Cc)
+    st[..., 0] = v.sum(2)
+    st[..., 1] = (v.astype(np.float64) ** 2).sum(2)
+
+
+def k_gn_small(L):
+    A = L["args"]
+    x1, C1, x2, C2, HW, groups, eps, gamma, beta, act, out = (u64(A[0]), i32(A[1]), u64(A[2]), i32(A[3]), i32(A[4]), i32(A[5]), f32(A[6]),
+                                                               u64(A[7]), u64(A[8]), i32(A[9]), u64(A[10]))
+    sl = SlabSrc.from_buffer_copy(A[11])
+    B = int(L["g"].split(",")[1])                         # grid (8, B)
+    M = B * HW
+    if sl.part:                                            # x1 arrives as split-K slabs (+ bias + time embedding + residual)
+        a = dev(sl.part, np.float32, sl.splitk * M * C1).reshape(sl.splitk, M, C1).sum(0)
+        if sl.bias:
+            a = a + dev(sl.bias, np.float32, C1)
+        if sl.temb:
+            for b in range(B):
+                a[b * HW:(b + 1) * HW] += dev(sl.temb + 4 * (b * sl.temb_bstride + sl.temb_off), np.float32, C1)
+        if sl.resid:
+            a = a + dev(sl.resid, f16, M * C1).astype(np.float32).reshape(M, C1)
+        a = r16(a)
+        if sl.raw_out:
+            dev(sl.raw_out, f16, M * C1)[:] = a.astype(f16).ravel()
+    else:
+        a = dev(x1, f16, M * C1).astype(np.float32).reshape(M, C1)
+    if C2:
+        a = np.concatenate([a, dev(x2, f16, M * C2).astype(np.float32).reshape(M, C2)], -1)
+    Cc = C1 + C2
+    gs = Cc // groups
+    g = a.reshape(B, HW, groups, gs).astype(np.float64)
+    mean = g.mean(axis=(1, 3), keepdims=True)
+    var = g.var(axis=(1, 3), keepdims=True)
+    y = ((g - mean) / np.sqrt(var + eps)).reshape(M, Cc).astype(np.float32) * dev(gamma, np.float32, Cc) + dev(beta, np.float32, Cc)
+    dev(out, f16, M * Cc)[:] = (silu(y) if act else y).astype(f16).ravel()
+
+
+def k_conv_t32(L):
+    a = FusedArgs.from_buffer_copy(L["args"][0])
+    TH = int(re.search(r"conv_t32I\w+?_?Li(\d+)E", L["sym"]).group(1))
+    head = a.out_nchw32 != 0
+    B, Hh, Ww = a.B, a.H, a.W
+    W9, W1 = decode_weights(a, 32 if head else 128)
+    xs = []
+    for i in range(a.nseg):
+        s = a.seg[i]
+        hs, ws = (Hh // 2, Ww // 2) if s.up else (Hh, Ww)
+        xs.append(dev(s.src, f16, B * hs * ws * s.C).astype(np.float32).reshape(B, hs, ws, s.C))
+    normed = a.gn_p1 != 0
+    assert normed or not a.ss, "scale/shift tables from memory: only the in-kernel finalisation is modelled"
+    if normed:
+        C1, C2 = a.gn_C1, a.ssC - a.gn_C1
+        tot = dev(a.gn_p1, np.float32, B * a.gn_ns1 * C1 * 2).reshape(B, a.gn_ns1, C1, 2).sum(1).astype(np.float64)
+        if C2:
+            tot = np.concatenate([tot, dev(a.gn_p2, np.float32, B * a.gn_ns2 * C2 * 2).reshape(B, a.gn_ns2, C2, 2).sum(1).astype(np.float64)], 1)
+        gam, bet = dev(a.gn_gamma, np.float32, a.ssC), dev(a.gn_beta, np.float32, a.ssC)
+        Cg = a.ssC // 32
+    outs = []
+    for b in range(B):
+        if normed:
+            g = tot[b].reshape(32, Cg, 2).sum(1)
+            n = Cg * a.gn_HW
+            mean = g[:, 0] / n
+            var = np.maximum(g[:, 1] / n - mean * mean, 0)
+            sc = (np.repeat(1.0 / np.sqrt(var + a.gn_eps), Cg) * gam).astype(np.float32)
+            sh = (bet - np.repeat(mean, Cg).astype(np.float32) * sc).astype(np.float32)
+        p9, p1 = [], []
+        for i in range(a.nseg):
+            s, x = a.seg[i], xs[i][b]
+            if s.taps == 9 and s.ss_off >= 0:
+                y = x * sc[s.ss_off:s.ss_off + s.C] + sh[s.ss_off:s.ss_off + s.C]
+                x = r16(LOG2E * (silu(y) if a.silu else y))
+            (p9 if s.taps == 9 else p1).append(up2(x) if s.up else x)
+        acc = conv3x3(np.concatenate(p9, -1), W9.reshape(a.Cout, -1, 3, 3))
+        if p1:
+            acc += (np.concatenate(p1, -1).reshape(Hh * Ww, -1) @ W1.T).reshape(Hh, Ww, -1)
+        if a.temb:
+            acc += dev(a.temb + 4 * (b * a.temb_bstride + a.temb_off), np.float32, a.Cout)
+        elif a.bias:
+            acc += dev(a.bias, np.float32, a.Cout)
+        outs.append(acc)
+    y = np.stack(outs)
+    if head:
+        dev(a.out, np.float32, B * a.Cout * Hh * Ww)[:] = y.transpose(0, 3, 1, 2).ravel()
+        return
+    y = r16(y)
+    if a.resid:
+        y = r16(y + dev(a.resid, f16, B * Hh * Ww * a.Cout).astype(np.float32).reshape(B, Hh, Ww, a.Cout))
+    dev(a.out, f16, y.size)[:] = y.astype(f16).ravel()
+    if a.stats:
+        tps = (Hh // TH) * (Ww // 16)
+        st = dev(a.stats, np.float32, B * tps * a.Cout * 2).reshape(B, tps, a.Cout, 2)
+        st[:] = 0
+        flat = y.reshape(B, Hh * Ww, a.Cout)
+        st[:, 0, :, 0] = flat.sum(1)                       # (the consumer adds the tiles up: the whole sample in tile 0)
+        st[:, 0, :, 1] = (flat.astype(np.float64) ** 2).sum(1)
+
+
+def k_conv_s(L):
+    a = TailArgs.from_buffer_copy(L["args"][0])
+    TM, NB, D = map(int, re.search(r"conv_sID[^_]*_?Li(\d+)ELi(\d+)ELi(\d+)E", L["sym"]).groups())
+    HW, Wd = 1 << a.hwlog, 1 << a.wlog
+    Hd, M = HW // Wd, a.B * HW
+    TN, NL = NB * 32, 2 * NB
+    attn = a.epi == 1
+    ncol = a.ntn * TN
+    rt = [Round.from_buffer_copy(bytes(dev(a.rounds + 32 * r, np.uint8, 32))) for r in range(a.nrounds)]
+
+    def rows_of(r):
+        Cs = r.row_bytes // 2
+        rows_src = M if r.mode == 0 else (M >> 2 if r.mode == 1 else M << 2)
+        x = dev(r.src, f16, rows_src * Cs).astype(np.float32).reshape(rows_src, Cs)
+        m = np.arange(M)
+        b, pix = m >> a.hwlog, m & (HW - 1)
+        y, xx = pix >> a.wlog, pix & (Wd - 1)
+        if r.mode == 0:
+            return x
+        if r.mode == 1:
+            return x[(b << (a.hwlog - 2)) + ((y >> 1) << (a.wlog - 1)) + (xx >> 1)]
+        py, px = r.phase >> 1, r.phase & 1
+        return x[(((b * Hd + y) * 2 + py) << (a.wlog + 1)) + 2 * xx + px]
+
+    def shifted(A, ts):
+        dy, dx = ts // 3 - 1, ts % 3 - 1
+        g = A.reshape(a.B, Hd, Wd, -1)
+        out = np.zeros_like(g)
+        out[:, max(0, -dy):Hd - max(0, dy), max(0, -dx):Wd - max(0, dx)] = g[:, max(0, dy):Hd - max(0, -dy), max(0, dx):Wd - max(0, -dx)]
+        return out.reshape(M, -1)
+
+    desc = dev(a.desc, np.uint32, 8 * a.maxsteps).reshape(8, a.maxsteps)
+    Wdense = {}
+    for w in range(8):
+        rnd = 0
+        for s in range(a.maxsteps):
+            e = int(desc[w, s])
+            if not (e & 0x2000):
+                ts, j = e & 15, (e >> 4) & 7
+                Wt = Wdense.setdefault((rnd, ts), np.zeros((ncol, 256), np.float32))
+                for nt in range(a.ntn):
+                    frag = dev(a.wgt + nt * a.tile_bytes + w * a.wave_bytes + s * NL * 1024, f16, NL * 512).astype(np.float32).reshape(2, NB, 64, 8)
+                    for ks in range(2):
+                        for nb in range(NB):
+                            for half in range(2):
+                                c = 32 * j + 16 * ks + 8 * half
+                                Wt[nt * TN + nb * 32:nt * TN + nb * 32 + 32, c:c + 8] += frag[ks, nb, 32 * half:32 * half + 32]
+            if e & 0x100:
+                rnd += 1
+    acc = np.zeros((M, ncol), np.float32)
+    cache = {}
+    for (rnd, ts), Wt in Wdense.items():
+        r = rt[rnd]
+        if rnd not in cache:
+            cache[rnd] = rows_of(r)[:, r.cbyte // 2:r.cbyte // 2 + 32 * r.nsub]
+        acc += shifted(cache[rnd], ts) @ Wt[:, :32 * r.nsub].T
+    col = np.arange(ncol)
+    cb = (col % TN >> 5) * a.Cout + (col // TN) * 32 + (col % TN & 31) if attn else col
+    nchan = 3 * a.Cout if attn else a.Cout
+    v = acc
+    if a.bias:
+        v = v + dev(a.bias, np.float32, nchan)[cb]
+    if a.temb:
+        for b in range(a.B):
+            v[b * HW:(b + 1) * HW] += dev(a.temb + 4 * (b * a.temb_bstride + a.temb_off), np.float32, nchan)[cb]
+    if attn:
+        qkv = v.reshape(M, a.ntn, 3, 4, 8)
+        q = qkv[:, :, 0].reshape(a.B, HW, a.ntn * 4, 8) * 0.35355339059327373
+        k = qkv[:, :, 1].reshape(a.B, HW, a.ntn * 4, 8)
+        vv = qkv[:, :, 2].reshape(a.B, HW, a.ntn * 4, 8)
+        sc = np.einsum("bthe,bshe->bhts", q, k)
+        p = np.exp(sc - sc.max(-1, keepdims=True))
+        p /= p.sum(-1, keepdims=True)
+        dev(a.attn_out, f16, M * a.Cout)[:] = np.einsum("bhts,bshe->bthe", p, vv).reshape(M, a.Cout).astype(f16).ravel()
+        return
+    v = v[:, :a.Cout]
+    if a.resid:
+        v = v + dev(a.resid, f16, M * a.Cout).astype(np.float32).reshape(M, a.Cout)
+    if a.raw_out:
+        dev(a.raw_out, f16, M * a.Cout)[:] = v.astype(f16).ravel()
+    for qi in range(a.nreq):
+        rq = a.req[qi]
+        g = v.reshape(a.B, HW, a.Cout // rq.gs, rq.gs).astype(np.float64)
+        mean = g.mean(axis=(1, 3), keepdims=True)
+        var = ((g - mean) ** 2).mean(axis=(1, 3), keepdims=True)
+        y = ((g - mean) / np.sqrt(var + a.eps)).reshape(M, a.Cout).astype(np.float32) * dev(rq.gamma, np.float32, a.Cout) + dev(rq.beta, np.float32, a.Cout)
+        dev(rq.out, f16, M * a.Cout)[:] = (silu(y) if rq.silu else y).astype(f16).ravel()
+
+
+KERNELS = {"temb_mlp_kernel": k_temb_mlp, "conv_igemm": k_igemm, "splitk_reduce_kernel": k_splitk_reduce, "conv_in_kernel": k_conv_in,
+           "gn_stats_kernel": k_gn_stats, "gn_small_kernel": k_gn_small, "conv_t32": k_conv_t32, "conv_s": k_conv_s}
+
+
+def main():
+    libpath, outdir = os.path.abspath(sys.argv[1]), sys.argv[2]
+    B = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    _lib.LIB_PATH = libpath
+    lib = _lib.load()
+    d = drive.Dev()
+    rs = np.random.RandomState(21)
+    h = C.c_void_p()
+    cfg = drive.unet_cfg(3, 6, 64, *drive.RES64, drive.F16, B)
+    _lib.check(lib.bndm_unet_create(C.byref(h), C.byref(cfg)), "create")
+    name, numel = C.create_string_buffer(200), C.c_int64()
+    params = []
+    given = np.load(sys.argv[4]) if len(sys.argv) > 4 else None      # state dict written by the test (the oracle's initialisation)
+    for i in range(lib.bndm_unet_num_params(h)):
+        _lib.check(lib.bndm_unet_param_info(h, i, name, 200, C.byref(numel)), "param_info")
+        if given is not None:
+            w = np.ascontiguousarray(given[name.value.decode()], np.float32).ravel()
+            assert w.size == numel.value, name.value
+        else:
+            w = (rs.standard_normal(numel.value) * 0.05).astype(np.float32)
+            if name.value.endswith(b"weight") and b"norm" in name.value.split(b".")[-2]:
+                w += 1.0
+        params.append([name.value.decode(), numel.value])
+        _lib.check(lib.bndm_unet_load_param(h, name.value, w.ctypes.data_as(C.c_void_p), numel.value), "load_param")
+    _lib.check(lib.bndm_unet_finalize(h), "finalize")
+    x = d.alloc(B * 3 * 64 * 64 * 4)
+    t = d.alloc(B * 4)
+    o = d.alloc(B * 6 * 64 * 64 * 4)
+    xin = rs.standard_normal((B, 3, 64, 64)).astype(np.float32)
+    tin = np.linspace(0.15, 0.85, B).astype(np.float32)
+    dev(x.value, np.float32, xin.size)[:] = xin.ravel()
+    dev(t.value, np.float32, B)[:] = tin
+    drive.mark("forward")
+    _lib.check(lib.bndm_unet_forward(h, x, t, o, B, None), "forward")
+    d.flush()
+    lines = open(os.environ["HIPMOCK_TRACE"]).read().splitlines()
+    body = dict(H.stages(lines))["forward"]
+    n = 0
+    for ln in body:
+        if ln.startswith("launch "):
+            L = H.parse_launch(ln)
+            KERNELS[L["name"]](L)
+            n += 1
+        else:
+            assert ln.startswith(("==", "event_record", "funcattr")), f"a call in the forward that the replay does not model: {ln[:80]}"
+    out = dev(o.value, np.float32, B * 6 * 64 * 64).reshape(B, 6, 64, 64).copy()
+    np.save(os.path.join(outdir, "exec_forward_out.npy"), out)
+    np.save(os.path.join(outdir, "exec_forward_x.npy"), xin)
+    np.save(os.path.join(outdir, "exec_forward_t.npy"), tin)
+    json.dump({"params": params, "seed": 21}, open(os.path.join(outdir, "exec_forward_params.json"), "w"))
+    print(f"OK replayed {n} launches; output rms {float(np.sqrt((out ** 2).mean())):.4f}")
+
+
+if __name__ == "__main__":
+    main()

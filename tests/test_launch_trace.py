@@ -97,3 +97,28 @@ def test_conv_s_launches_compute_their_layers(workdir):
     dict and must have the requested group size."""
     out = H.run_script("check_conv_s.py", H.PRODUCT_LIB, workdir)
     assert "OK 51 conv_s launches" in out, out[-2000:]
+
+
+def test_forward_replayed_through_kernel_models_equals_the_oracle(workdir):
+    """One forward at batch 2, executed on the CPU through the ENGINE'S OWN launch list: every recorded launch is handed to a
+    numpy model of its kernel's contract that reads and writes the very buffers the kernel would (tests/hipmock/exec_forward.py),
+    and the fp32 result equals oracle/unet_oracle.py on the same weights and inputs.  Covers the launch order and every buffer
+    hand-over between launches (skip connections, concatenations, normalised copies, partial sums, split-K slabs, the
+    time-embedding table) on top of the per-launch checks above.  Host side only: no device code runs."""
+    import numpy as np
+    import torch
+    from oracle import unet_oracle as UO
+    cfg = UO.make_config(64, 3, 6)
+    sd = UO.init_params(cfg, seed=0, perturb_norm=0.1)       # the initialisation the GPU parity tests use
+    wfile = os.path.join(workdir, "exec_forward_weights.npz")
+    np.savez(wfile, **{k: v.numpy() for k, v in sd.items()})
+    out = H.run_script("exec_forward.py", H.PRODUCT_LIB, workdir, workdir, 2, wfile)
+    os.remove(wfile)
+    assert "OK replayed" in out, out[-2000:]
+    x = torch.from_numpy(np.load(os.path.join(workdir, "exec_forward_x.npy")))
+    t = torch.from_numpy(np.load(os.path.join(workdir, "exec_forward_t.npy")))
+    want = UO.forward(sd, cfg, x, t).numpy()
+    got = np.load(os.path.join(workdir, "exec_forward_out.npy"))
+    rel = float(np.linalg.norm((got - want).astype(np.float64)) / np.linalg.norm(want.astype(np.float64)))
+    print(f"forward replayed through the kernel models vs the oracle: rel-L2 {rel:.3e}")
+    assert rel <= 2e-3, f"forward replayed through the kernel models vs the oracle: rel-L2 {rel:.3e}"
