@@ -203,6 +203,26 @@ def k_gn_stats(L):
     st[..., 1] = (v.astype(np.float64) ** 2).sum(2)
 
 
+def k_gn_finalize2(L):
+    A = L["args"]
+    p1, ns1, C1, p2, ns2, C2, HW, groups, eps, gamma, beta, ss = (u64(A[0]), i32(A[1]), i32(A[2]), u64(A[3]), i32(A[4]), i32(A[5]), i32(A[6]),
+                                                                  i32(A[7]), f32(A[8]), u64(A[9]), u64(A[10]), u64(A[11]))
+    B = int(L["g"].split(",")[1])
+    Cc = C1 + C2
+    tot = dev(p1, np.float32, B * ns1 * C1 * 2).reshape(B, ns1, C1, 2).sum(1).astype(np.float64)
+    if C2:
+        tot = np.concatenate([tot, dev(p2, np.float32, B * ns2 * C2 * 2).reshape(B, ns2, C2, 2).sum(1).astype(np.float64)], 1)
+    Cg = Cc // groups
+    g = tot.reshape(B, groups, Cg, 2).sum(2)
+    n = Cg * HW
+    mean = g[..., 0] / n
+    var = np.maximum(g[..., 1] / n - mean * mean, 0)
+    sc = (np.repeat(1.0 / np.sqrt(var + eps), Cg, axis=1) * dev(gamma, np.float32, Cc)).astype(np.float32)
+    sh = (dev(beta, np.float32, Cc) - np.repeat(mean, Cg, axis=1).astype(np.float32) * sc).astype(np.float32)
+    out = dev(ss, np.float32, B * 2 * Cc).reshape(B, 2, Cc)
+    out[:, 0], out[:, 1] = sc, sh
+
+
 def k_gn_small(L):
     A = L["args"]
     x1, C1, x2, C2, HW, groups, eps, gamma, beta, act, out = (u64(A[0]), i32(A[1]), u64(A[2]), i32(A[3]), i32(A[4]), i32(A[5]), f32(A[6]),
@@ -247,7 +267,7 @@ def k_conv_t32(L):
         hs, ws = (Hh // 2, Ww // 2) if s.up else (Hh, Ww)
         xs.append(dev(s.src, f16, B * hs * ws * s.C).astype(np.float32).reshape(B, hs, ws, s.C))
     normed = a.gn_p1 != 0
-    assert normed or not a.ss, "scale/shift tables from memory: only the in-kernel finalisation is modelled"
+    table = dev(a.ss, np.float32, B * 2 * a.ssC).reshape(B, 2, a.ssC) if (a.ss and not normed) else None   # gn_finalize2's table
     if normed:
         C1, C2 = a.gn_C1, a.ssC - a.gn_C1
         tot = dev(a.gn_p1, np.float32, B * a.gn_ns1 * C1 * 2).reshape(B, a.gn_ns1, C1, 2).sum(1).astype(np.float64)
@@ -264,6 +284,8 @@ def k_conv_t32(L):
             var = np.maximum(g[:, 1] / n - mean * mean, 0)
             sc = (np.repeat(1.0 / np.sqrt(var + a.gn_eps), Cg) * gam).astype(np.float32)
             sh = (bet - np.repeat(mean, Cg).astype(np.float32) * sc).astype(np.float32)
+        elif table is not None:
+            sc, sh = table[b, 0], table[b, 1]
         p9, p1 = [], []
         for i in range(a.nseg):
             s, x = a.seg[i], xs[i][b]
@@ -385,60 +407,110 @@ def k_conv_s(L):
         dev(rq.out, f16, M * a.Cout)[:] = (silu(y) if rq.silu else y).astype(f16).ravel()
 
 
+def k_iadb_step(L):
+    A = L["args"]
+    x, dd, da, dg, Cc, Cout, HW4, total4 = u64(A[0]), u64(A[1]), f32(A[2]), f32(A[3]), i32(A[4]), i32(A[5]), i32(A[6]), u64(A[7])
+    HW = HW4 * 4
+    B = total4 // (Cc * HW4)
+    xv = dev(x, np.float32, B * Cc * HW).reshape(B, Cc, HW)
+    dv = dev(dd, np.float32, B * Cout * HW).reshape(B, Cout, HW)
+    r = xv + np.float32(da) * dv[:, :Cc]                       # products and sums rounded separately, as steps.hip does
+    if Cout == 2 * Cc:
+        r = r + np.float32(dg) * dv[:, Cc:]
+    xv[:] = r
+
+
+def k_ddim_step(L):
+    A = L["args"]
+    x, eps, sat, s1at, sap, s1ap, clip, n = u64(A[0]), u64(A[1]), f32(A[2]), f32(A[3]), f32(A[4]), f32(A[5]), f32(A[6]), u64(A[7])
+    xv, e = dev(x, np.float32, n), dev(eps, np.float32, n)
+    x0 = (xv - np.float32(s1at) * e) / np.float32(sat)
+    if clip > 0:
+        x0 = np.clip(x0, -clip, clip)
+    xv[:] = np.float32(sap) * x0 + np.float32(s1ap) * e
+
+
 KERNELS = {"temb_mlp_kernel": k_temb_mlp, "conv_igemm": k_igemm, "splitk_reduce_kernel": k_splitk_reduce, "conv_in_kernel": k_conv_in,
-           "gn_stats_kernel": k_gn_stats, "gn_small_kernel": k_gn_small, "conv_t32": k_conv_t32, "conv_s": k_conv_s}
+           "gn_stats_kernel": k_gn_stats, "gn_small_kernel": k_gn_small, "gn_finalize2_kernel": k_gn_finalize2, "conv_t32": k_conv_t32, "conv_s": k_conv_s,
+           "iadb_step_kernel": k_iadb_step, "ddim_step_kernel": k_ddim_step}
+
+# what is run: (in, out channels, resolution, block_out_channels / attention levels, batch, mode)
+CASES = {
+    "c2": (3, 6, 64, drive.RES64, 2, "forward"),           # cat_res64, UNet 3 -> 6
+    "c2loop": (3, 6, 64, drive.RES64, 2, "iadb"),          # ... two steps of the in-engine IADB loop with snapshots
+    "c3loop": (3, 3, 64, drive.RES64, 1, "ddim"),          # church_res64: two steps of the in-engine DDIM loop
+    "c4": (3, 6, 128, drive.RES128, 1, "forward"),         # celeba_res128
+    "c5": (4, 8, 64, drive.RES64, 2, "forward"),           # latent UNet 4 -> 8
+    "cond": (6, 3, 128, drive.RES128, 1, "cond"),          # super-resolution sampler: x (3) + conditioning (3) -> 3, two steps
+}
+T_IN, DA, DG = [1.0, 0.5], [-0.5, -0.5], [-0.3, -0.2]
+DDIM = [990.0, 0.9, 0.43588989, 0.92, 0.39191836, 980.0, 0.92, 0.39191836, 0.94, 0.34117444]
 
 
 def main():
-    libpath, outdir = os.path.abspath(sys.argv[1]), sys.argv[2]
-    B = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    libpath, outdir, case = os.path.abspath(sys.argv[1]), sys.argv[2], sys.argv[3]
+    cin, cout, res, layout, B, mode = CASES[case]
     _lib.LIB_PATH = libpath
     lib = _lib.load()
     d = drive.Dev()
     rs = np.random.RandomState(21)
     h = C.c_void_p()
-    cfg = drive.unet_cfg(3, 6, 64, *drive.RES64, drive.F16, B)
+    cfg = drive.unet_cfg(cin, cout, res, *layout, drive.F16, B)
     _lib.check(lib.bndm_unet_create(C.byref(h), C.byref(cfg)), "create")
     name, numel = C.create_string_buffer(200), C.c_int64()
-    params = []
-    given = np.load(sys.argv[4]) if len(sys.argv) > 4 else None      # state dict written by the test (the oracle's initialisation)
+    given = np.load(sys.argv[4])                           # state dict written by the test (the oracle's initialisation)
     for i in range(lib.bndm_unet_num_params(h)):
         _lib.check(lib.bndm_unet_param_info(h, i, name, 200, C.byref(numel)), "param_info")
-        if given is not None:
-            w = np.ascontiguousarray(given[name.value.decode()], np.float32).ravel()
-            assert w.size == numel.value, name.value
-        else:
-            w = (rs.standard_normal(numel.value) * 0.05).astype(np.float32)
-            if name.value.endswith(b"weight") and b"norm" in name.value.split(b".")[-2]:
-                w += 1.0
-        params.append([name.value.decode(), numel.value])
+        w = np.ascontiguousarray(given[name.value.decode()], np.float32).ravel()
+        assert w.size == numel.value, name.value
         _lib.check(lib.bndm_unet_load_param(h, name.value, w.ctypes.data_as(C.c_void_p), numel.value), "load_param")
     _lib.check(lib.bndm_unet_finalize(h), "finalize")
-    x = d.alloc(B * 3 * 64 * 64 * 4)
-    t = d.alloc(B * 4)
-    o = d.alloc(B * 6 * 64 * 64 * 4)
-    xin = rs.standard_normal((B, 3, 64, 64)).astype(np.float32)
-    tin = np.linspace(0.15, 0.85, B).astype(np.float32)
+    cx = 3 if mode == "cond" else cin                      # channels of the sampler state
+    x = d.alloc(B * cx * res * res * 4)
+    xin = rs.standard_normal((B, cx, res, res)).astype(np.float32)
     dev(x.value, np.float32, xin.size)[:] = xin.ravel()
-    dev(t.value, np.float32, B)[:] = tin
-    drive.mark("forward")
-    _lib.check(lib.bndm_unet_forward(h, x, t, o, B, None), "forward")
+    np.save(os.path.join(outdir, f"exec_{case}_x.npy"), xin)
+    drive.mark("run")
+    if mode == "forward":
+        t, o = d.alloc(B * 4), d.alloc(B * cout * res * res * 4)
+        tin = np.linspace(0.15, 0.85, B).astype(np.float32)
+        dev(t.value, np.float32, B)[:] = tin
+        np.save(os.path.join(outdir, f"exec_{case}_t.npy"), tin)
+        _lib.check(lib.bndm_unet_forward(h, x, t, o, B, None), "forward")
+        result = lambda: dev(o.value, np.float32, B * cout * res * res).reshape(B, cout, res, res).copy()
+    elif mode in ("iadb", "cond"):
+        extra = None
+        if mode == "cond":
+            extra = d.alloc(B * 3 * res * res * 4)
+            ein = rs.standard_normal((B, 3, res, res)).astype(np.float32)
+            dev(extra.value, np.float32, ein.size)[:] = ein.ravel()
+            np.save(os.path.join(outdir, f"exec_{case}_extra.npy"), ein)
+        snaps = d.alloc(2 * B * cx * res * res * 4)
+        _lib.check(lib.bndm_unet_sample_iadb(h, x, extra, B, cx, 2, drive.farr(T_IN), drive.farr(DA), drive.farr(DG),
+                                             (C.c_uint8 * 2)(1, 1), snaps, None), "sample_iadb")
+        result = lambda: dev(snaps.value, np.float32, 2 * B * cx * res * res).reshape(2, B, cx, res, res).copy()
+    else:
+        _lib.check(lib.bndm_unet_sample_ddim(h, x, B, 2, drive.farr(DDIM), 1.0, None), "sample_ddim")
+        result = lambda: dev(x.value, np.float32, B * cx * res * res).reshape(B, cx, res, res).copy()
     d.flush()
+    dev(x.value, np.float32, xin.size)[:] = xin.ravel()    # (nothing ran: the state is still x0; written again for clarity)
     lines = open(os.environ["HIPMOCK_TRACE"]).read().splitlines()
-    body = dict(H.stages(lines))["forward"]
     n = 0
-    for ln in body:
+    for ln in dict(H.stages(lines))["run"]:
         if ln.startswith("launch "):
             L = H.parse_launch(ln)
             KERNELS[L["name"]](L)
             n += 1
+        elif ln.startswith("memcpy_async") and "src=0x" in ln:             # device -> device (snapshots): at its place in the order
+            m = re.search(r"dst=(0x[0-9a-f]+) src=(0x[0-9a-f]+) n=(\d+)", ln)
+            dst, src, nb = int(m.group(1), 16), int(m.group(2), 16), int(m.group(3))
+            dev(dst, np.uint8, nb)[:] = dev(src, np.uint8, nb)
         else:
-            assert ln.startswith(("==", "event_record", "funcattr")), f"a call in the forward that the replay does not model: {ln[:80]}"
-    out = dev(o.value, np.float32, B * 6 * 64 * 64).reshape(B, 6, 64, 64).copy()
-    np.save(os.path.join(outdir, "exec_forward_out.npy"), out)
-    np.save(os.path.join(outdir, "exec_forward_x.npy"), xin)
-    np.save(os.path.join(outdir, "exec_forward_t.npy"), tin)
-    json.dump({"params": params, "seed": 21}, open(os.path.join(outdir, "exec_forward_params.json"), "w"))
+            # host -> device copies (schedule tables) were carried out when they were recorded; allocations, attributes, events
+            assert ln.startswith(("==", "event_record", "funcattr", "memcpy", "malloc", "free", "hostmalloc", "stream_", "device_sync")), \
+                f"a call the replay does not model: {ln[:80]}"
+    out = result()
+    np.save(os.path.join(outdir, f"exec_{case}_out.npy"), out)
     print(f"OK replayed {n} launches; output rms {float(np.sqrt((out ** 2).mean())):.4f}")
 
 

@@ -99,26 +99,54 @@ def test_conv_s_launches_compute_their_layers(workdir):
     assert "OK 51 conv_s launches" in out, out[-2000:]
 
 
-def test_forward_replayed_through_kernel_models_equals_the_oracle(workdir):
-    """One forward at batch 2, executed on the CPU through the ENGINE'S OWN launch list: every recorded launch is handed to a
-    numpy model of its kernel's contract that reads and writes the very buffers the kernel would (tests/hipmock/exec_forward.py),
-    and the fp32 result equals oracle/unet_oracle.py on the same weights and inputs.  Covers the launch order and every buffer
-    hand-over between launches (skip connections, concatenations, normalised copies, partial sums, split-K slabs, the
-    time-embedding table) on top of the per-launch checks above.  Host side only: no device code runs."""
+REPLAY_CASES = {   # tests/hipmock/exec_forward.py CASES: (in, out, resolution, batch, mode); tolerance per forward as on the GPU
+    "c2": (3, 6, 64, 2, "forward"), "c2loop": (3, 6, 64, 2, "iadb"), "c3loop": (3, 3, 64, 1, "ddim"),
+    "c4": (3, 6, 128, 1, "forward"), "c5": (4, 8, 64, 2, "forward"), "cond": (6, 3, 128, 1, "cond"),
+}
+
+
+@pytest.mark.parametrize("case", list(REPLAY_CASES))
+def test_replay_through_kernel_models_equals_the_oracle(case, workdir):
+    """The engine's own launch list, executed on the CPU: every launch the library records for a forward (or two steps of an
+    in-engine IADB / DDIM / conditional loop) is handed to a numpy model of its kernel's contract that reads and writes the
+    very buffers the kernel would (tests/hipmock/exec_forward.py), and the result equals oracle/unet_oracle.py + the samplers'
+    update rules on the same weights and inputs.  Covers the launch order and every buffer hand-over between launches (skip
+    connections, concatenations, normalised copies, partial sums, split-K slabs, the per-schedule time-embedding table,
+    snapshots) on top of the per-launch checks above, for BASELINE.json's layouts.  Host side only: no device code runs."""
     import numpy as np
     import torch
     from oracle import unet_oracle as UO
-    cfg = UO.make_config(64, 3, 6)
+    from tests.hipmock.exec_forward import DA, DDIM, DG, T_IN
+    cin, cout, res, B, mode = REPLAY_CASES[case]
+    cfg = UO.make_config(res, cin, cout)
     sd = UO.init_params(cfg, seed=0, perturb_norm=0.1)       # the initialisation the GPU parity tests use
-    wfile = os.path.join(workdir, "exec_forward_weights.npz")
+    wfile = os.path.join(workdir, f"exec_{case}_weights.npz")
     np.savez(wfile, **{k: v.numpy() for k, v in sd.items()})
-    out = H.run_script("exec_forward.py", H.PRODUCT_LIB, workdir, workdir, 2, wfile)
+    out = H.run_script("exec_forward.py", H.PRODUCT_LIB, workdir, workdir, case, wfile)
     os.remove(wfile)
     assert "OK replayed" in out, out[-2000:]
-    x = torch.from_numpy(np.load(os.path.join(workdir, "exec_forward_x.npy")))
-    t = torch.from_numpy(np.load(os.path.join(workdir, "exec_forward_t.npy")))
-    want = UO.forward(sd, cfg, x, t).numpy()
-    got = np.load(os.path.join(workdir, "exec_forward_out.npy"))
-    rel = float(np.linalg.norm((got - want).astype(np.float64)) / np.linalg.norm(want.astype(np.float64)))
-    print(f"forward replayed through the kernel models vs the oracle: rel-L2 {rel:.3e}")
-    assert rel <= 2e-3, f"forward replayed through the kernel models vs the oracle: rel-L2 {rel:.3e}"
+    load = lambda what: torch.from_numpy(np.load(os.path.join(workdir, f"exec_{case}_{what}.npy")))
+    x = load("x")
+    if mode == "forward":
+        want = UO.forward(sd, cfg, x, load("t"))
+    elif mode in ("iadb", "cond"):
+        extra = load("extra") if mode == "cond" else None
+        snaps = []
+        for s in range(2):                                   # utils.py:196-226 / iadb_bn.py:384-438 with explicit tables
+            d = UO.forward(sd, cfg, x if extra is None else torch.cat([x, extra], 1), T_IN[s])
+            x = x + DA[s] * d[:, :x.shape[1]]
+            if cout == 2 * x.shape[1]:
+                x = x + DG[s] * d[:, x.shape[1]:]
+            snaps.append(x)
+        want = torch.stack(snaps)
+    else:
+        for s in range(2):                                   # ddim_diffusers.py:674-681, eps-prediction, eta 0, clip 1
+            t, sat, s1at, sap, s1ap = DDIM[5 * s:5 * s + 5]
+            eps = UO.forward(sd, cfg, x, t)
+            x0 = ((x - s1at * eps) / sat).clamp(-1.0, 1.0)
+            x = sap * x0 + s1ap * eps
+        want = x
+    got = load("out")
+    rel = float((got - want).double().norm() / want.double().norm())
+    print(f"{case}: replay through the kernel models vs the oracle: rel-L2 {rel:.3e}")
+    assert rel <= 2e-3, f"{case}: rel-L2 {rel:.3e}"
