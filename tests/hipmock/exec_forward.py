@@ -302,6 +302,19 @@ def k_conv_t32(L):
             acc += dev(a.bias, np.float32, a.Cout)
         outs.append(acc)
     y = np.stack(outs)
+    if head and (a.out_nchw32 & 2):
+        # candidate contract (tools/experiments/head_euler_step.patch): the head applies the IADB Euler update to the sampler state
+        # instead of storing d -- resid = x (fp32 NCHW), temb_bstride / temb_off = the bits of da / dg, bit 2 = two-headed output
+        da = np.frombuffer(np.int32(a.temb_bstride).tobytes(), np.float32)[0]
+        dg = np.frombuffer(np.int32(a.temb_off).tobytes(), np.float32)[0]
+        Cx = a.Cout // 2 if a.out_nchw32 & 4 else a.Cout
+        xv = dev(a.resid, np.float32, B * Cx * Hh * Ww).reshape(B, Cx, Hh, Ww)
+        dd = y.transpose(0, 3, 1, 2)
+        r = xv + da * dd[:, :Cx]
+        if a.out_nchw32 & 4:
+            r = r + dg * dd[:, Cx:2 * Cx]
+        xv[:] = r
+        return
     if head:
         dev(a.out, np.float32, B * a.Cout * Hh * Ww)[:] = y.transpose(0, 3, 1, 2).ravel()
         return
@@ -464,6 +477,10 @@ def main():
         w = np.ascontiguousarray(given[name.value.decode()], np.float32).ravel()
         assert w.size == numel.value, name.value
         _lib.check(lib.bndm_unet_load_param(h, name.value, w.ctypes.data_as(C.c_void_p), numel.value), "load_param")
+    lanes = int(os.environ.get("EXEC_LANES", "1"))           # candidate (tools/experiments/lanes.patch): chains of launches
+    if lanes > 1:
+        lib.bndm_unet_set_lanes.restype, lib.bndm_unet_set_lanes.argtypes = C.c_int, [C.c_void_p, C.c_int, C.c_int]
+        _lib.check(lib.bndm_unet_set_lanes(h, lanes, int(os.environ.get("EXEC_LANE_FLAGS", "0"))), "set_lanes")
     _lib.check(lib.bndm_unet_finalize(h), "finalize")
     cx = 3 if mode == "cond" else cin                      # channels of the sampler state
     x = d.alloc(B * cx * res * res * 4)

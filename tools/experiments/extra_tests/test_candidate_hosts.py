@@ -57,3 +57,52 @@ def test_euler_step_in_the_head_launch(scenario, flags, cout, tmp_path):
                 assert da == struct.unpack("<f", struct.pack("<f", -1.0 / steps))[0] and dg == struct.unpack("<f", struct.pack("<f", -0.5 / steps))[0]
         elif mark.startswith("forward"):
             assert len(heads) == 1 and struct.unpack_from("<i", heads[0]["args"][0], 176)[0] == 1
+
+
+# ---- whole loops replayed on the CPU through a candidate's own launch list (tests/hipmock/exec_forward.py) vs the oracle ----
+def _replay(libname, case, tmp_path, env=None):
+    import numpy as np
+    import torch
+    from oracle import unet_oracle as UO
+    from tests.hipmock.exec_forward import DA, DG, T_IN
+    from tests.test_launch_trace import REPLAY_CASES
+    cin, cout, res, B, mode = REPLAY_CASES[case]
+    assert mode == "iadb"
+    cfg = UO.make_config(res, cin, cout)
+    sd = UO.init_params(cfg, seed=0, perturb_norm=0.1)
+    wd = str(tmp_path)
+    wfile = os.path.join(wd, "w.npz")
+    np.savez(wfile, **{k: v.numpy() for k, v in sd.items()})
+    old = dict(os.environ)
+    os.environ.update(env or {})
+    try:
+        out = H.run_script("exec_forward.py", lib(libname), wd, wd, case, wfile)
+    finally:
+        os.environ.clear()
+        os.environ.update(old)
+    os.remove(wfile)
+    assert "OK replayed" in out
+    x = torch.from_numpy(np.load(os.path.join(wd, f"exec_{case}_x.npy")))
+    snaps = []
+    for s in range(2):
+        d = UO.forward(sd, cfg, x, T_IN[s])
+        x = x + DA[s] * d[:, :3] + DG[s] * d[:, 3:]
+        snaps.append(x)
+    got = torch.from_numpy(np.load(os.path.join(wd, f"exec_{case}_out.npy")))
+    rel = float((got - torch.stack(snaps)).double().norm() / torch.stack(snaps).double().norm())
+    assert rel <= 2e-3, rel
+    return out
+
+
+def test_euler_step_candidate_loop_equals_the_oracle(tmp_path):
+    """lib_v15: the head launch's new contract (x updated in place, no iadb_step launch) replayed end to end"""
+    out = _replay("lib_v15.so", "c2loop", tmp_path)
+    base = _replay("../bndm_amd/libbndm_hip.so", "c2loop", tmp_path)
+    count = lambda o: int(o.split("replayed")[1].split()[0])
+    assert count(out) == count(base) - 2                     # one launch fewer per step
+
+
+@pytest.mark.parametrize("lanes,flags", [(2, 0), (2, 4), (2, 2)])
+def test_lanes_candidate_loop_equals_the_oracle(lanes, flags, tmp_path):
+    """lib_lanes: two chains on their own buffer copies, replayed in enqueue order, give the one-chain result"""
+    _replay("lib_lanes.so", "c2loop", tmp_path, {"EXEC_LANES": str(lanes), "EXEC_LANE_FLAGS": str(flags)})
