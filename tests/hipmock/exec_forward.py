@@ -31,6 +31,40 @@ from tests.hipmock.check_conv_s import Round, TailArgs  # noqa: E402
 from tests.hipmock.check_conv_t32 import LOG2E, FusedArgs, conv3x3, decode_weights, dev, silu, up2  # noqa: E402
 
 f16 = np.float16
+# candidate layout (tools/experiments/round4_pairstats_sumsfirst_th32.patch): GroupNorm partial sums per channel PAIR,
+# [B][slabs][C / 2][2] = (sum, sum of squares) over the slab's pixels and both channels of the pair
+PAIR = os.environ.get("EXEC_PAIRSTATS") == "1"
+
+
+def stat_write(st_addr, v, B, nslab):
+    """v [B, nslab, pixels, C] stored values -> the partial-sum buffer in the layout in force"""
+    Cc = v.shape[-1]
+    if PAIR:
+        st = dev(st_addr, np.float32, B * nslab * Cc).reshape(B, nslab, Cc // 2, 2)
+        p = v.reshape(B, nslab, -1, Cc // 2, 2)
+        st[..., 0] = p.sum((2, 4))
+        st[..., 1] = (p.astype(np.float64) ** 2).sum((2, 4))
+    else:
+        st = dev(st_addr, np.float32, B * nslab * Cc * 2).reshape(B, nslab, Cc, 2)
+        st[..., 0] = v.sum(2)
+        st[..., 1] = (v.astype(np.float64) ** 2).sum(2)
+
+
+def stat_write_into(dst, v):
+    """dst [B, units, 2] <- sums of v [B, pixels, C] (units = channels or channel pairs)"""
+    if PAIR:
+        p = v.reshape(v.shape[0], v.shape[1], -1, 2)
+        dst[..., 0] = p.sum((1, 3))
+        dst[..., 1] = (p.astype(np.float64) ** 2).sum((1, 3))
+    else:
+        dst[..., 0] = v.sum(1)
+        dst[..., 1] = (v.astype(np.float64) ** 2).sum(1)
+
+
+def stat_totals(addr, B, ns, Cc):
+    """-> [B, units, 2] sums over the slabs; units = channels, or channel pairs in the candidate layout"""
+    u = Cc // 2 if PAIR else Cc
+    return dev(addr, np.float32, B * ns * u * 2).reshape(B, ns, u, 2).sum(1).astype(np.float64)
 
 
 def r16(x):
@@ -183,10 +217,7 @@ def k_conv_in(L):
         o[b] = y.reshape(Hh * Ww, C0).astype(f16)
     if stats:
         ns = (Hh * Ww) >> 7
-        st = dev(stats, np.float32, B * ns * C0 * 2).reshape(B, ns, C0, 2)
-        v = o.astype(np.float32).reshape(B, ns, 128, C0)
-        st[..., 0] = v.sum(2)
-        st[..., 1] = (v.astype(np.float64) ** 2).sum(2)
+        stat_write(stats, o.astype(np.float32).reshape(B, ns, 128, C0), B, ns)
 
 
 def k_gn_stats(L):
@@ -197,10 +228,7 @@ def k_gn_stats(L):
     if C2:
         x = np.concatenate([x, dev(x2, f16, B * HW * C2).astype(np.float32).reshape(B, HW, C2)], -1)
     Cc = C1 + C2
-    st = dev(partial, np.float32, B * nslab * Cc * 2).reshape(B, nslab, Cc, 2)
-    v = x.reshape(B, nslab, HW // nslab, Cc)
-    st[..., 0] = v.sum(2)
-    st[..., 1] = (v.astype(np.float64) ** 2).sum(2)
+    stat_write(partial, x.reshape(B, nslab, HW // nslab, Cc), B, nslab)
 
 
 def k_gn_finalize2(L):
@@ -209,11 +237,11 @@ def k_gn_finalize2(L):
                                                                   i32(A[7]), f32(A[8]), u64(A[9]), u64(A[10]), u64(A[11]))
     B = int(L["g"].split(",")[1])
     Cc = C1 + C2
-    tot = dev(p1, np.float32, B * ns1 * C1 * 2).reshape(B, ns1, C1, 2).sum(1).astype(np.float64)
+    tot = stat_totals(p1, B, ns1, C1)
     if C2:
-        tot = np.concatenate([tot, dev(p2, np.float32, B * ns2 * C2 * 2).reshape(B, ns2, C2, 2).sum(1).astype(np.float64)], 1)
+        tot = np.concatenate([tot, stat_totals(p2, B, ns2, C2)], 1)
     Cg = Cc // groups
-    g = tot.reshape(B, groups, Cg, 2).sum(2)
+    g = tot.reshape(B, groups, -1, 2).sum(2)
     n = Cg * HW
     mean = g[..., 0] / n
     var = np.maximum(g[..., 1] / n - mean * mean, 0)
@@ -270,15 +298,15 @@ def k_conv_t32(L):
     table = dev(a.ss, np.float32, B * 2 * a.ssC).reshape(B, 2, a.ssC) if (a.ss and not normed) else None   # gn_finalize2's table
     if normed:
         C1, C2 = a.gn_C1, a.ssC - a.gn_C1
-        tot = dev(a.gn_p1, np.float32, B * a.gn_ns1 * C1 * 2).reshape(B, a.gn_ns1, C1, 2).sum(1).astype(np.float64)
+        tot = stat_totals(a.gn_p1, B, a.gn_ns1, C1)
         if C2:
-            tot = np.concatenate([tot, dev(a.gn_p2, np.float32, B * a.gn_ns2 * C2 * 2).reshape(B, a.gn_ns2, C2, 2).sum(1).astype(np.float64)], 1)
+            tot = np.concatenate([tot, stat_totals(a.gn_p2, B, a.gn_ns2, C2)], 1)
         gam, bet = dev(a.gn_gamma, np.float32, a.ssC), dev(a.gn_beta, np.float32, a.ssC)
         Cg = a.ssC // 32
     outs = []
     for b in range(B):
         if normed:
-            g = tot[b].reshape(32, Cg, 2).sum(1)
+            g = tot[b].reshape(32, -1, 2).sum(1)
             n = Cg * a.gn_HW
             mean = g[:, 0] / n
             var = np.maximum(g[:, 1] / n - mean * mean, 0)
@@ -324,11 +352,10 @@ def k_conv_t32(L):
     dev(a.out, f16, y.size)[:] = y.astype(f16).ravel()
     if a.stats:
         tps = (Hh // TH) * (Ww // 16)
-        st = dev(a.stats, np.float32, B * tps * a.Cout * 2).reshape(B, tps, a.Cout, 2)
-        st[:] = 0
-        flat = y.reshape(B, Hh * Ww, a.Cout)
-        st[:, 0, :, 0] = flat.sum(1)                       # (the consumer adds the tiles up: the whole sample in tile 0)
-        st[:, 0, :, 1] = (flat.astype(np.float64) ** 2).sum(1)
+        u = a.Cout // 2 if PAIR else a.Cout                 # (the consumer adds the tiles up: the whole sample in tile 0)
+        dev(a.stats, np.float32, B * tps * u * 2)[:] = 0
+        tmp = dev(a.stats, np.float32, B * tps * u * 2).reshape(B, tps, u, 2)
+        stat_write_into(tmp[:, 0], y.reshape(B, Hh * Ww, a.Cout))
 
 
 def k_conv_s(L):

@@ -106,3 +106,37 @@ def test_euler_step_candidate_loop_equals_the_oracle(tmp_path):
 def test_lanes_candidate_loop_equals_the_oracle(lanes, flags, tmp_path):
     """lib_lanes: two chains on their own buffer copies, replayed in enqueue order, give the one-chain result"""
     _replay("lib_lanes.so", "c2loop", tmp_path, {"EXEC_LANES": str(lanes), "EXEC_LANE_FLAGS": str(flags)})
+
+
+@pytest.mark.parametrize("case", ["c2", "c4"])
+def test_pair_statistics_candidate_forward_equals_the_oracle(case, tmp_path):
+    """lib_v8 (round-4 patch): GroupNorm partial sums per channel pair in every producer and consumer -- the forward replayed with
+    the models switched to that layout (EXEC_PAIRSTATS=1) reproduces the oracle; with the product's layout it must NOT (the
+    switch really is the layout)"""
+    import numpy as np
+    import torch
+    from oracle import unet_oracle as UO
+    from tests.test_launch_trace import REPLAY_CASES
+    cin, cout, res, B, mode = REPLAY_CASES[case]
+    cfg = UO.make_config(res, cin, cout)
+    sd = UO.init_params(cfg, seed=0, perturb_norm=0.1)
+    wd = str(tmp_path)
+    wfile = os.path.join(wd, "w.npz")
+    np.savez(wfile, **{k: v.numpy() for k, v in sd.items()})
+    rels = {}
+    for pair in ("1", "0"):
+        os.environ["EXEC_PAIRSTATS"] = pair
+        try:
+            out = H.run_script("exec_forward.py", lib("lib_v8.so"), wd, wd, case, wfile)
+        except AssertionError:
+            rels[pair] = float("inf")                        # (the wrong layout may also run out of a buffer's bounds)
+            continue
+        finally:
+            os.environ.pop("EXEC_PAIRSTATS", None)
+        x = torch.from_numpy(np.load(os.path.join(wd, f"exec_{case}_x.npy")))
+        t = torch.from_numpy(np.load(os.path.join(wd, f"exec_{case}_t.npy")))
+        want = UO.forward(sd, cfg, x, t)
+        got = torch.from_numpy(np.load(os.path.join(wd, f"exec_{case}_out.npy")))
+        rels[pair] = float((got - want).double().norm() / want.double().norm())
+    os.remove(wfile)
+    assert rels["1"] <= 2e-3 and rels["0"] > 1e-2, rels
