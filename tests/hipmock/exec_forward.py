@@ -470,7 +470,40 @@ def k_ddim_step(L):
     xv[:] = np.float32(sap) * x0 + np.float32(s1ap) * e
 
 
-KERNELS = {"temb_mlp_kernel": k_temb_mlp, "conv_igemm": k_igemm, "splitk_reduce_kernel": k_splitk_reduce, "conv_in_kernel": k_conv_in,
+def k_pointwise_f32(L):
+    A = L["args"]
+    z, w, bias, out, Cin, Cout, HW, total = u64(A[0]), u64(A[1]), u64(A[2]), u64(A[3]), i32(A[4]), i32(A[5]), i32(A[6]), u64(A[7])
+    B = total // (Cout * HW)
+    zz = dev(z, np.float32, B * Cin * HW).reshape(B, Cin, HW)
+    o = np.einsum("mc,bcp->bmp", dev(w, np.float32, Cout * Cin).reshape(Cout, Cin), zz) + dev(bias, np.float32, Cout)[None, :, None]
+    dev(out, np.float32, B * Cout * HW)[:] = o.astype(np.float32).ravel()
+
+
+def k_gn_apply(L):
+    A = L["args"]
+    x1, C1, x2, C2, ss, HW, total_chunks, act, out = u64(A[0]), i32(A[1]), u64(A[2]), i32(A[3]), u64(A[4]), i32(A[5]), u64(A[6]), i32(A[7]), u64(A[8])
+    Cc = C1 + C2
+    M = total_chunks * 8 // Cc
+    B = M // HW
+    x = dev(x1, f16, M * C1).astype(np.float32).reshape(M, C1)
+    if C2:
+        x = np.concatenate([x, dev(x2, f16, M * C2).astype(np.float32).reshape(M, C2)], -1)
+    t = dev(ss, np.float32, B * 2 * Cc).reshape(B, 2, Cc)
+    y = x.reshape(B, HW, Cc) * t[:, None, 0] + t[:, None, 1]
+    dev(out, f16, M * Cc)[:] = (silu(y) if act else y).astype(f16).ravel()
+
+
+def k_softmax_rows(L):
+    A = L["args"]
+    sp, rows, n, scale = u64(A[0]), i32(A[1]), i32(A[2]), f32(A[3])
+    m = dev(sp, f16, rows * n).reshape(rows, n)
+    v = m.astype(np.float32) * np.float32(scale)
+    p = np.exp(v - v.max(-1, keepdims=True))
+    m[:] = (p / p.sum(-1, keepdims=True)).astype(f16)
+
+
+KERNELS = {"pointwise_f32_kernel": k_pointwise_f32, "gn_apply_kernel": k_gn_apply, "softmax_rows_kernel": k_softmax_rows,
+           "temb_mlp_kernel": k_temb_mlp, "conv_igemm": k_igemm, "splitk_reduce_kernel": k_splitk_reduce, "conv_in_kernel": k_conv_in,
            "gn_stats_kernel": k_gn_stats, "gn_small_kernel": k_gn_small, "gn_finalize2_kernel": k_gn_finalize2, "conv_t32": k_conv_t32, "conv_s": k_conv_s,
            "iadb_step_kernel": k_iadb_step, "ddim_step_kernel": k_ddim_step}
 
@@ -482,6 +515,7 @@ CASES = {
     "c4": (3, 6, 128, drive.RES128, 1, "forward"),         # celeba_res128
     "c5": (4, 8, 64, drive.RES64, 2, "forward"),           # latent UNet 4 -> 8
     "cond": (6, 3, 128, drive.RES128, 1, "cond"),          # super-resolution sampler: x (3) + conditioning (3) -> 3, two steps
+    "vae16": (4, 3, 16, None, 1, "vae"),                   # AutoencoderKL decoder, full layout, 16x16 latent -> 128 px
 }
 T_IN, DA, DG = [1.0, 0.5], [-0.5, -0.5], [-0.3, -0.2]
 DDIM = [990.0, 0.9, 0.43588989, 0.92, 0.39191836, 980.0, 0.92, 0.39191836, 0.94, 0.34117444]
@@ -495,8 +529,16 @@ def main():
     d = drive.Dev()
     rs = np.random.RandomState(21)
     h = C.c_void_p()
-    cfg = drive.unet_cfg(cin, cout, res, *layout, drive.F16, B)
-    _lib.check(lib.bndm_unet_create(C.byref(h), C.byref(cfg)), "create")
+    if mode == "vae":
+        cfg = _lib.VaeConfig()
+        cfg.latent_channels, cfg.out_channels, cfg.latent_resolution, cfg.num_levels = cin, cout, res, 4
+        for i, v in enumerate((128, 256, 512, 512)):
+            cfg.block_out_channels[i] = v
+        cfg.layers_per_block, cfg.dtype, cfg.max_batch = 2, drive.F16, B
+        _lib.check(lib.bndm_vae_decoder_create(C.byref(h), C.byref(cfg)), "vae create")
+    else:
+        cfg = drive.unet_cfg(cin, cout, res, *layout, drive.F16, B)
+        _lib.check(lib.bndm_unet_create(C.byref(h), C.byref(cfg)), "create")
     name, numel = C.create_string_buffer(200), C.c_int64()
     given = np.load(sys.argv[4])                           # state dict written by the test (the oracle's initialisation)
     for i in range(lib.bndm_unet_num_params(h)):
@@ -522,6 +564,10 @@ def main():
         np.save(os.path.join(outdir, f"exec_{case}_t.npy"), tin)
         _lib.check(lib.bndm_unet_forward(h, x, t, o, B, None), "forward")
         result = lambda: dev(o.value, np.float32, B * cout * res * res).reshape(B, cout, res, res).copy()
+    elif mode == "vae":
+        o = d.alloc(B * cout * (8 * res) ** 2 * 4)
+        _lib.check(lib.bndm_vae_decode(h, x, o, B, None), "vae_decode")
+        result = lambda: dev(o.value, np.float32, B * cout * (8 * res) ** 2).reshape(B, cout, 8 * res, 8 * res).copy()
     elif mode in ("iadb", "cond"):
         extra = None
         if mode == "cond":
