@@ -502,7 +502,18 @@ def k_softmax_rows(L):
     m[:] = (p / p.sum(-1, keepdims=True)).astype(f16)
 
 
-KERNELS = {"pointwise_f32_kernel": k_pointwise_f32, "gn_apply_kernel": k_gn_apply, "softmax_rows_kernel": k_softmax_rows,
+def k_attention(L):
+    A = L["args"]
+    qkv, out, B, T, Cc = u64(A[0]), u64(A[1]), i32(A[2]), i32(A[3]), i32(A[4])
+    m = dev(qkv, f16, B * T * 3 * Cc).astype(np.float32).reshape(B, T, 3, Cc // 8, 8)
+    q, k, v = m[:, :, 0] * 0.35355339059327373, m[:, :, 1], m[:, :, 2]
+    sc = np.einsum("bthe,bshe->bhts", q, k)
+    p = np.exp(sc - sc.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    dev(out, f16, B * T * Cc)[:] = np.einsum("bhts,bshe->bthe", p, v).astype(f16).ravel()
+
+
+KERNELS = {"attention_kernel": k_attention, "pointwise_f32_kernel": k_pointwise_f32, "gn_apply_kernel": k_gn_apply, "softmax_rows_kernel": k_softmax_rows,
            "temb_mlp_kernel": k_temb_mlp, "conv_igemm": k_igemm, "splitk_reduce_kernel": k_splitk_reduce, "conv_in_kernel": k_conv_in,
            "gn_stats_kernel": k_gn_stats, "gn_small_kernel": k_gn_small, "gn_finalize2_kernel": k_gn_finalize2, "conv_t32": k_conv_t32, "conv_s": k_conv_s,
            "iadb_step_kernel": k_iadb_step, "ddim_step_kernel": k_ddim_step}
@@ -516,6 +527,11 @@ CASES = {
     "c5": (4, 8, 64, drive.RES64, 2, "forward"),           # latent UNet 4 -> 8
     "cond": (6, 3, 128, drive.RES128, 1, "cond"),          # super-resolution sampler: x (3) + conditioning (3) -> 3, two steps
     "vae16": (4, 3, 16, None, 1, "vae"),                   # AutoencoderKL decoder, full layout, 16x16 latent -> 128 px
+    # layouts the reference ships beyond the benchmark configurations (tests/test_gpu_layouts.py) and first-level widths 64 / 256
+    "lat256": (4, 8, 32, ((128, 256, 256), 2, 0), 5, "forward"),       # latent celeba_res256: 64-token attention, ragged batch
+    "w64": (3, 6, 64, ((64, 128, 128), 2, 0), 3, "forward"),           # groups of two channels; 64 + 128 = 192-channel concats
+    "w64b": (3, 6, 64, ((64, 64, 128, 256), 3, 0), 2, "forward"),
+    "w256": (3, 6, 32, ((256, 256, 512), 2, 0), 2, "forward"),
 }
 T_IN, DA, DG = [1.0, 0.5], [-0.5, -0.5], [-0.3, -0.2]
 DDIM = [990.0, 0.9, 0.43588989, 0.92, 0.39191836, 980.0, 0.92, 0.39191836, 0.94, 0.34117444]

@@ -99,11 +99,8 @@ def test_conv_s_launches_compute_their_layers(workdir):
     assert "OK 51 conv_s launches" in out, out[-2000:]
 
 
-REPLAY_CASES = {   # tests/hipmock/exec_forward.py CASES: (in, out, resolution, batch, mode); tolerance per forward as on the GPU
-    "c2": (3, 6, 64, 2, "forward"), "c2loop": (3, 6, 64, 2, "iadb"), "c3loop": (3, 3, 64, 1, "ddim"),
-    "c4": (3, 6, 128, 1, "forward"), "c5": (4, 8, 64, 2, "forward"), "cond": (6, 3, 128, 1, "cond"),
-    "vae16": (4, 3, 16, 1, "vae"),
-}
+from tests.hipmock.exec_forward import CASES as _CASES     # (in, out, resolution, layout, batch, mode) per case
+REPLAY_CASES = {k: (v[0], v[1], v[2], v[4], v[5]) for k, v in _CASES.items()}
 
 
 @pytest.mark.parametrize("case", list(REPLAY_CASES))
@@ -124,7 +121,11 @@ def test_replay_through_kernel_models_equals_the_oracle(case, workdir):
         cfg = VO.make_config()
         sd = VO.init_params(cfg, seed=0, perturb_norm=0.1)
     else:
-        cfg = UO.make_config(res, cin, cout)
+        boc, da_, ua_ = _CASES[case][3]
+        cfg = dict(in_channels=cin, out_channels=cout, block_out_channels=tuple(boc), layers_per_block=2,
+                   down_attn=tuple(i == da_ for i in range(len(boc))), up_attn=tuple(i == ua_ for i in range(len(boc))))
+        if len(boc) >= 6:
+            assert cfg == UO.make_config(res, cin, cout)     # the reference's constructor arguments for this resolution
         sd = UO.init_params(cfg, seed=0, perturb_norm=0.1)   # the initialisation the GPU parity tests use
     wfile = os.path.join(workdir, f"exec_{case}_weights.npz")
     np.savez(wfile, **{k: v.numpy() for k, v in sd.items()})
