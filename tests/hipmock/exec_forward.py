@@ -617,7 +617,12 @@ def main():
                 f"a call the replay does not model: {ln[:80]}"
     out = result()
     np.save(os.path.join(outdir, f"exec_{case}_out.npy"), out)
-    print(f"OK replayed {n} launches; output rms {float(np.sqrt((out ** 2).mean())):.4f}")
+    kinds = set()
+    kern, lab, fl = C.create_string_buffer(128), C.create_string_buffer(256), C.c_double()
+    for i in range(lib.bndm_unet_num_ops(h)):
+        _lib.check(lib.bndm_unet_op_info(h, i, kern, 128, lab, 256, C.byref(fl)), "op_info")
+        kinds.add(kern.value.decode())
+    print(f"OK replayed {n} launches; output rms {float(np.sqrt((out ** 2).mean())):.4f}; kernels {sorted(kinds)}")
 
 
 if __name__ == "__main__":

@@ -124,8 +124,11 @@ def test_pair_statistics_candidate_forward_equals_the_oracle(case, tmp_path):
     wfile = os.path.join(wd, "w.npz")
     np.savez(wfile, **{k: v.numpy() for k, v in sd.items()})
     rels = {}
-    for pair in ("1", "0"):
-        os.environ["EXEC_PAIRSTATS"] = pair
+    for pair in ("1", "0", "th32"):
+        os.environ["EXEC_PAIRSTATS"] = "0" if pair == "0" else "1"
+        if pair == "th32":                                   # 512-pixel tiles wherever the shape allows: other slab counts
+            os.environ["BNDM_TH32_MIN"] = "1"
+            os.environ["BNDM_TH16_MIN"] = "1"                # (256-pixel tiles first, also at this small batch)
         try:
             out = H.run_script("exec_forward.py", lib("lib_v8.so"), wd, wd, case, wfile)
         except AssertionError:
@@ -133,10 +136,14 @@ def test_pair_statistics_candidate_forward_equals_the_oracle(case, tmp_path):
             continue
         finally:
             os.environ.pop("EXEC_PAIRSTATS", None)
+            os.environ.pop("BNDM_TH32_MIN", None)
+            os.environ.pop("BNDM_TH16_MIN", None)
+        if pair == "th32":
+            assert "TH=32" in out, "BNDM_TH32_MIN=1 selected no conv_t32<TH=32> launch"
         x = torch.from_numpy(np.load(os.path.join(wd, f"exec_{case}_x.npy")))
         t = torch.from_numpy(np.load(os.path.join(wd, f"exec_{case}_t.npy")))
         want = UO.forward(sd, cfg, x, t)
         got = torch.from_numpy(np.load(os.path.join(wd, f"exec_{case}_out.npy")))
         rels[pair] = float((got - want).double().norm() / want.double().norm())
     os.remove(wfile)
-    assert rels["1"] <= 2e-3 and rels["0"] > 1e-2, rels
+    assert rels["1"] <= 2e-3 and rels["th32"] <= 2e-3 and rels["0"] > 1e-2, rels
