@@ -85,11 +85,12 @@ def group_norm(x, gamma, beta, eps, groups=32):
     return (y * gamma + beta).astype(np.float32)
 
 
-def decode_weights(a, rows):
+def decode_weights(a, rows, read16=None):
     """packed upload -> (W9 [Cout][sum of 3x3 channels][9], W1 [Cout][sum of 1x1 channels]) as the K loop consumes them"""
     nsteps = sum(a.seg[i].taps * (a.seg[i].C // 32) for i in range(a.nseg))
     ntn = (a.Cout + rows - 1) // rows
-    wp = dev(a.Wgt, np.float16, ntn * nsteps * rows * 32).astype(np.float32).reshape(ntn, nsteps, rows, 4, 8)
+    read16 = read16 or (lambda addr, n: dev(addr, np.float16, n).astype(np.float32))
+    wp = read16(a.Wgt, ntn * nsteps * rows * 32).reshape(ntn, nsteps, rows, 4, 8)
     r = np.arange(rows)
     C9 = sum(a.seg[i].C for i in range(a.nseg) if a.seg[i].taps == 9)
     C1 = sum(a.seg[i].C for i in range(a.nseg) if a.seg[i].taps == 1)

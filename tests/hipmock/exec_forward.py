@@ -67,8 +67,33 @@ def stat_totals(addr, B, ns, Cc):
     return dev(addr, np.float32, B * ns * u * 2).reshape(B, ns, u, 2).sum(1).astype(np.float64)
 
 
+BF16 = False                                               # set by main() from the case: 16-bit storage type of the handle
+
+
+def to16(x):
+    """fp32 array -> the handle's 16-bit storage (uint16 bit patterns), round to nearest even"""
+    x = np.ascontiguousarray(x, np.float32)
+    if not BF16:
+        return x.astype(f16).view(np.uint16)
+    u = x.view(np.uint32)
+    return ((u + (0x7FFF + ((u >> 16) & 1))) >> 16).astype(np.uint16)
+
+
+def from16(u):
+    u = np.asarray(u, np.uint16)
+    return (u.astype(np.uint32) << 16).view(np.float32) if BF16 else u.view(f16).astype(np.float32)
+
+
+def rd16(addr, n):
+    return from16(dev(addr, np.uint16, n))
+
+
+def wr16(addr, x):
+    dev(addr, np.uint16, x.size)[:] = to16(x).ravel()
+
+
 def r16(x):
-    return x.astype(f16).astype(np.float32)
+    return from16(to16(x)).reshape(x.shape)
 
 
 class CSeg(C.Structure):
@@ -114,14 +139,14 @@ def k_temb_mlp(L):
     emb = np.concatenate([np.cos(ang), np.sin(ang)], 1).astype(np.float32)            # flip_sin_to_cos
     h1 = silu(emb @ dev(W1t, np.float32, C0 * D).reshape(C0, D) + dev(b1, np.float32, D))
     v = h1 @ dev(W2t, np.float32, D * D).reshape(D, D) + dev(b2, np.float32, D)
-    dev(act, f16, B * D)[:] = silu(v).astype(f16).ravel()
+    wr16(act, silu(v))
 
 
 def igemm_weights(a):
     rows = -(-a.Cout // 128) * 128 if a.wtiled else None
     if a.wtiled:
         ks = a.Ktot // 64
-        wt = dev(a.Wgt, f16, rows * a.Ktot).astype(np.float32).reshape(rows // 128, ks, 128, 8, 8)
+        wt = rd16(a.Wgt, rows * a.Ktot).reshape(rows // 128, ks, 128, 8, 8)
         wp = np.zeros((rows, a.Ktot), np.float32)
         r = np.arange(128)
         for j in range(8):
@@ -132,7 +157,7 @@ def igemm_weights(a):
                         wp[nt * 128 + rr, s * 64 + g[rr] * 8:s * 64 + g[rr] * 8 + 8] = wt[nt, s, rr, j]
         return wp[:a.Cout]
     # plain [Cout_pad][Ktot]: the row padding is unknown here, but only the first Cout rows matter
-    return dev(a.Wgt, f16, a.Cout * a.Ktot).astype(np.float32).reshape(a.Cout, a.Ktot)
+    return rd16(a.Wgt, a.Cout * a.Ktot).reshape(a.Cout, a.Ktot)
 
 
 def k_igemm(L):
@@ -151,7 +176,7 @@ def k_igemm(L):
             hs, ws = Hh // 2, Ww // 2
         else:
             hs, ws = Hh, Ww
-        x = dev(s.src, f16, B * hs * ws * s.C).astype(np.float32).reshape(B, hs, ws, s.C)
+        x = rd16(s.src, B * hs * ws * s.C).reshape(B, hs, ws, s.C)
         Wseg = Wm[:, koff:koff + s.taps * s.C].reshape(a.Cout, s.taps, s.C)
         for b in range(B):
             xb = up2(x[b]) if s.up else x[b]
@@ -181,8 +206,8 @@ def k_igemm(L):
         return
     assert epi == 0
     if a.resid:
-        acc += dev(a.resid, f16, M * a.Cout).astype(np.float32).reshape(M, a.Cout)
-    dev(a.out, f16, M * a.Cout)[:] = acc.astype(f16).ravel()
+        acc += rd16(a.resid, M * a.Cout).reshape(M, a.Cout)
+    wr16(a.out, acc)
 
 
 def k_splitk_reduce(L):
@@ -197,8 +222,8 @@ def k_splitk_reduce(L):
         for b in range(a.B):
             s[b << logHW:(b + 1) << logHW] += dev(a.temb + 4 * (b * a.temb_bstride + a.temb_off), np.float32, a.Cout)
     if a.resid:
-        s = s + dev(a.resid, f16, M * a.Cout).astype(np.float32).reshape(M, a.Cout)
-    dev(a.out, f16, M * a.Cout)[:] = s.astype(f16).ravel()
+        s = s + rd16(a.resid, M * a.Cout).reshape(M, a.Cout)
+    wr16(a.out, s)
 
 
 def k_conv_in(L):
@@ -210,23 +235,21 @@ def k_conv_in(L):
     if Ce:
         xin = np.concatenate([xin, dev(extra, np.float32, B * Ce * Hh * Ww).reshape(B, Ce, Hh, Ww)], 1)
     Cin = Cx + Ce
-    W = dev(W16, f16, C0 * KP).astype(np.float32).reshape(C0, KP)[:, :9 * Cin].reshape(C0, Cin, 3, 3)   # k = ci * 9 + ky * 3 + kx
-    o = dev(out, f16, B * Hh * Ww * C0).reshape(B, Hh * Ww, C0)
-    for b in range(B):
-        y = conv3x3(r16(xin[b].transpose(1, 2, 0)), W) + dev(bias, np.float32, C0)
-        o[b] = y.reshape(Hh * Ww, C0).astype(f16)
+    W = rd16(W16, C0 * KP).reshape(C0, KP)[:, :9 * Cin].reshape(C0, Cin, 3, 3)   # k = ci * 9 + ky * 3 + kx
+    o = np.stack([r16((conv3x3(r16(xin[b].transpose(1, 2, 0)), W) + dev(bias, np.float32, C0)).reshape(Hh * Ww, C0)) for b in range(B)])
+    wr16(out, o)
     if stats:
         ns = (Hh * Ww) >> 7
-        stat_write(stats, o.astype(np.float32).reshape(B, ns, 128, C0), B, ns)
+        stat_write(stats, o.reshape(B, ns, 128, C0), B, ns)
 
 
 def k_gn_stats(L):
     A = L["args"]
     x1, C1, x2, C2, HW, partial, nslab = u64(A[0]), i32(A[1]), u64(A[2]), i32(A[3]), i32(A[4]), u64(A[5]), i32(A[6])
     B = int(L["g"].split(",")[1])
-    x = dev(x1, f16, B * HW * C1).astype(np.float32).reshape(B, HW, C1)
+    x = rd16(x1, B * HW * C1).reshape(B, HW, C1)
     if C2:
-        x = np.concatenate([x, dev(x2, f16, B * HW * C2).astype(np.float32).reshape(B, HW, C2)], -1)
+        x = np.concatenate([x, rd16(x2, B * HW * C2).reshape(B, HW, C2)], -1)
     Cc = C1 + C2
     stat_write(partial, x.reshape(B, nslab, HW // nslab, Cc), B, nslab)
 
@@ -266,21 +289,21 @@ def k_gn_small(L):
             for b in range(B):
                 a[b * HW:(b + 1) * HW] += dev(sl.temb + 4 * (b * sl.temb_bstride + sl.temb_off), np.float32, C1)
         if sl.resid:
-            a = a + dev(sl.resid, f16, M * C1).astype(np.float32).reshape(M, C1)
+            a = a + rd16(sl.resid, M * C1).reshape(M, C1)
         a = r16(a)
         if sl.raw_out:
-            dev(sl.raw_out, f16, M * C1)[:] = a.astype(f16).ravel()
+            wr16(sl.raw_out, a)
     else:
-        a = dev(x1, f16, M * C1).astype(np.float32).reshape(M, C1)
+        a = rd16(x1, M * C1).reshape(M, C1)
     if C2:
-        a = np.concatenate([a, dev(x2, f16, M * C2).astype(np.float32).reshape(M, C2)], -1)
+        a = np.concatenate([a, rd16(x2, M * C2).reshape(M, C2)], -1)
     Cc = C1 + C2
     gs = Cc // groups
     g = a.reshape(B, HW, groups, gs).astype(np.float64)
     mean = g.mean(axis=(1, 3), keepdims=True)
     var = g.var(axis=(1, 3), keepdims=True)
     y = ((g - mean) / np.sqrt(var + eps)).reshape(M, Cc).astype(np.float32) * dev(gamma, np.float32, Cc) + dev(beta, np.float32, Cc)
-    dev(out, f16, M * Cc)[:] = (silu(y) if act else y).astype(f16).ravel()
+    wr16(out, (silu(y) if act else y))
 
 
 def k_conv_t32(L):
@@ -288,12 +311,12 @@ def k_conv_t32(L):
     TH = int(re.search(r"conv_t32I\w+?_?Li(\d+)E", L["sym"]).group(1))
     head = a.out_nchw32 != 0
     B, Hh, Ww = a.B, a.H, a.W
-    W9, W1 = decode_weights(a, 32 if head else 128)
+    W9, W1 = decode_weights(a, 32 if head else 128, rd16)
     xs = []
     for i in range(a.nseg):
         s = a.seg[i]
         hs, ws = (Hh // 2, Ww // 2) if s.up else (Hh, Ww)
-        xs.append(dev(s.src, f16, B * hs * ws * s.C).astype(np.float32).reshape(B, hs, ws, s.C))
+        xs.append(rd16(s.src, B * hs * ws * s.C).reshape(B, hs, ws, s.C))
     normed = a.gn_p1 != 0
     table = dev(a.ss, np.float32, B * 2 * a.ssC).reshape(B, 2, a.ssC) if (a.ss and not normed) else None   # gn_finalize2's table
     if normed:
@@ -348,8 +371,8 @@ def k_conv_t32(L):
         return
     y = r16(y)
     if a.resid:
-        y = r16(y + dev(a.resid, f16, B * Hh * Ww * a.Cout).astype(np.float32).reshape(B, Hh, Ww, a.Cout))
-    dev(a.out, f16, y.size)[:] = y.astype(f16).ravel()
+        y = r16(y + rd16(a.resid, B * Hh * Ww * a.Cout).reshape(B, Hh, Ww, a.Cout))
+    wr16(a.out, y)
     if a.stats:
         tps = (Hh // TH) * (Ww // 16)
         u = a.Cout // 2 if PAIR else a.Cout                 # (the consumer adds the tiles up: the whole sample in tile 0)
@@ -371,7 +394,7 @@ def k_conv_s(L):
     def rows_of(r):
         Cs = r.row_bytes // 2
         rows_src = M if r.mode == 0 else (M >> 2 if r.mode == 1 else M << 2)
-        x = dev(r.src, f16, rows_src * Cs).astype(np.float32).reshape(rows_src, Cs)
+        x = rd16(r.src, rows_src * Cs).reshape(rows_src, Cs)
         m = np.arange(M)
         b, pix = m >> a.hwlog, m & (HW - 1)
         y, xx = pix >> a.wlog, pix & (Wd - 1)
@@ -399,7 +422,7 @@ def k_conv_s(L):
                 ts, j = e & 15, (e >> 4) & 7
                 Wt = Wdense.setdefault((rnd, ts), np.zeros((ncol, 256), np.float32))
                 for nt in range(a.ntn):
-                    frag = dev(a.wgt + nt * a.tile_bytes + w * a.wave_bytes + s * NL * 1024, f16, NL * 512).astype(np.float32).reshape(2, NB, 64, 8)
+                    frag = rd16(a.wgt + nt * a.tile_bytes + w * a.wave_bytes + s * NL * 1024, NL * 512).reshape(2, NB, 64, 8)
                     for ks in range(2):
                         for nb in range(NB):
                             for half in range(2):
@@ -431,20 +454,20 @@ def k_conv_s(L):
         sc = np.einsum("bthe,bshe->bhts", q, k)
         p = np.exp(sc - sc.max(-1, keepdims=True))
         p /= p.sum(-1, keepdims=True)
-        dev(a.attn_out, f16, M * a.Cout)[:] = np.einsum("bhts,bshe->bthe", p, vv).reshape(M, a.Cout).astype(f16).ravel()
+        wr16(a.attn_out, np.einsum("bhts,bshe->bthe", p, vv).reshape(M, a.Cout))
         return
     v = v[:, :a.Cout]
     if a.resid:
-        v = v + dev(a.resid, f16, M * a.Cout).astype(np.float32).reshape(M, a.Cout)
+        v = v + rd16(a.resid, M * a.Cout).reshape(M, a.Cout)
     if a.raw_out:
-        dev(a.raw_out, f16, M * a.Cout)[:] = v.astype(f16).ravel()
+        wr16(a.raw_out, v)
     for qi in range(a.nreq):
         rq = a.req[qi]
         g = v.reshape(a.B, HW, a.Cout // rq.gs, rq.gs).astype(np.float64)
         mean = g.mean(axis=(1, 3), keepdims=True)
         var = ((g - mean) ** 2).mean(axis=(1, 3), keepdims=True)
         y = ((g - mean) / np.sqrt(var + a.eps)).reshape(M, a.Cout).astype(np.float32) * dev(rq.gamma, np.float32, a.Cout) + dev(rq.beta, np.float32, a.Cout)
-        dev(rq.out, f16, M * a.Cout)[:] = (silu(y) if rq.silu else y).astype(f16).ravel()
+        wr16(rq.out, (silu(y) if rq.silu else y))
 
 
 def k_iadb_step(L):
@@ -485,32 +508,31 @@ def k_gn_apply(L):
     Cc = C1 + C2
     M = total_chunks * 8 // Cc
     B = M // HW
-    x = dev(x1, f16, M * C1).astype(np.float32).reshape(M, C1)
+    x = rd16(x1, M * C1).reshape(M, C1)
     if C2:
-        x = np.concatenate([x, dev(x2, f16, M * C2).astype(np.float32).reshape(M, C2)], -1)
+        x = np.concatenate([x, rd16(x2, M * C2).reshape(M, C2)], -1)
     t = dev(ss, np.float32, B * 2 * Cc).reshape(B, 2, Cc)
     y = x.reshape(B, HW, Cc) * t[:, None, 0] + t[:, None, 1]
-    dev(out, f16, M * Cc)[:] = (silu(y) if act else y).astype(f16).ravel()
+    wr16(out, (silu(y) if act else y))
 
 
 def k_softmax_rows(L):
     A = L["args"]
     sp, rows, n, scale = u64(A[0]), i32(A[1]), i32(A[2]), f32(A[3])
-    m = dev(sp, f16, rows * n).reshape(rows, n)
-    v = m.astype(np.float32) * np.float32(scale)
+    v = rd16(sp, rows * n).reshape(rows, n) * np.float32(scale)
     p = np.exp(v - v.max(-1, keepdims=True))
-    m[:] = (p / p.sum(-1, keepdims=True)).astype(f16)
+    wr16(sp, p / p.sum(-1, keepdims=True))
 
 
 def k_attention(L):
     A = L["args"]
     qkv, out, B, T, Cc = u64(A[0]), u64(A[1]), i32(A[2]), i32(A[3]), i32(A[4])
-    m = dev(qkv, f16, B * T * 3 * Cc).astype(np.float32).reshape(B, T, 3, Cc // 8, 8)
+    m = rd16(qkv, B * T * 3 * Cc).reshape(B, T, 3, Cc // 8, 8)
     q, k, v = m[:, :, 0] * 0.35355339059327373, m[:, :, 1], m[:, :, 2]
     sc = np.einsum("bthe,bshe->bhts", q, k)
     p = np.exp(sc - sc.max(-1, keepdims=True))
     p /= p.sum(-1, keepdims=True)
-    dev(out, f16, B * T * Cc)[:] = np.einsum("bhts,bshe->bthe", p, v).astype(f16).ravel()
+    wr16(out, np.einsum("bhts,bshe->bthe", p, v))
 
 
 KERNELS = {"attention_kernel": k_attention, "pointwise_f32_kernel": k_pointwise_f32, "gn_apply_kernel": k_gn_apply, "softmax_rows_kernel": k_softmax_rows,
@@ -532,6 +554,7 @@ CASES = {
     "w64": (3, 6, 64, ((64, 128, 128), 2, 0), 3, "forward"),           # groups of two channels; 64 + 128 = 192-channel concats
     "w64b": (3, 6, 64, ((64, 64, 128, 256), 3, 0), 2, "forward"),
     "w256": (3, 6, 32, ((256, 256, 512), 2, 0), 2, "forward"),
+    "c2bf16": (3, 6, 64, drive.RES64, 1, "forward"),       # bf16 storage / MFMA inputs (case name ends in bf16)
 }
 T_IN, DA, DG = [1.0, 0.5], [-0.5, -0.5], [-0.3, -0.2]
 DDIM = [990.0, 0.9, 0.43588989, 0.92, 0.39191836, 980.0, 0.92, 0.39191836, 0.94, 0.34117444]
@@ -540,6 +563,9 @@ DDIM = [990.0, 0.9, 0.43588989, 0.92, 0.39191836, 980.0, 0.92, 0.39191836, 0.94,
 def main():
     libpath, outdir, case = os.path.abspath(sys.argv[1]), sys.argv[2], sys.argv[3]
     cin, cout, res, layout, B, mode = CASES[case]
+    global BF16
+    BF16 = case.endswith("bf16")
+    dtype = drive.BF16 if BF16 else drive.F16
     _lib.LIB_PATH = libpath
     lib = _lib.load()
     d = drive.Dev()
@@ -550,10 +576,10 @@ def main():
         cfg.latent_channels, cfg.out_channels, cfg.latent_resolution, cfg.num_levels = cin, cout, res, 4
         for i, v in enumerate((128, 256, 512, 512)):
             cfg.block_out_channels[i] = v
-        cfg.layers_per_block, cfg.dtype, cfg.max_batch = 2, drive.F16, B
+        cfg.layers_per_block, cfg.dtype, cfg.max_batch = 2, dtype, B
         _lib.check(lib.bndm_vae_decoder_create(C.byref(h), C.byref(cfg)), "vae create")
     else:
-        cfg = drive.unet_cfg(cin, cout, res, *layout, drive.F16, B)
+        cfg = drive.unet_cfg(cin, cout, res, *layout, dtype, B)
         _lib.check(lib.bndm_unet_create(C.byref(h), C.byref(cfg)), "create")
     name, numel = C.create_string_buffer(200), C.c_int64()
     given = np.load(sys.argv[4])                           # state dict written by the test (the oracle's initialisation)
