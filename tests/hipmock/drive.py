@@ -114,6 +114,14 @@ def scenario(lib, dev, name, lanes, flags):
         forward(lib, dev, h, 2, 3, 6, 64)
         mark("sample_iadb B=6 steps=2")
         iadb(lib, dev, h, 6, 3, 3, 64, 2)
+    elif name == "b500":                                   # the reference's shipped batch at 64 px (scripts/sampling/cat_res64_test.sh:5)
+        h = make_unet(lib, unet_cfg(3, 6, 64, *RES64, F16, 500), lanes, flags)
+        mark("sample_iadb B=500 steps=1")
+        iadb(lib, dev, h, 500, 3, 3, 64, 1)
+    elif name == "b200":                                   # ... and at 128 px (cat_res128_test.sh:4)
+        h = make_unet(lib, unet_cfg(3, 6, 128, *RES128, F16, 200), lanes, flags)
+        mark("sample_iadb B=200 steps=1")
+        iadb(lib, dev, h, 200, 3, 3, 128, 1)
     elif name == "c2bf16":
         h = make_unet(lib, unet_cfg(3, 6, 64, *RES64, BF16, 64), lanes, flags)
         mark("forward B=64")

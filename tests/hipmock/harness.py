@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 PRODUCT_LIB = os.path.join(ROOT, "bndm_amd", "libbndm_hip.so")
-SCENARIOS = ("c2", "c2bf16", "c3", "c4", "c5", "cond", "f32", "noise")
+SCENARIOS = ("c2", "c2bf16", "c3", "c4", "c5", "cond", "f32", "noise", "b500", "b200")
 DEV_LO, DEV_HI = 0x200000000000, 0x200000000000 + (1 << 40)          # hipmock.cpp: kBase, kSpan
 
 
