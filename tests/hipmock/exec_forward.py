@@ -36,9 +36,13 @@ f16 = np.float16
 PAIR = os.environ.get("EXEC_PAIRSTATS") == "1"
 
 
+STAT_SHAPE = {}                                            # partial-sum buffer -> (slabs per sample, channels) as its producer wrote it
+
+
 def stat_write(st_addr, v, B, nslab):
     """v [B, nslab, pixels, C] stored values -> the partial-sum buffer in the layout in force"""
     Cc = v.shape[-1]
+    STAT_SHAPE[st_addr] = (nslab, Cc)
     if PAIR:
         st = dev(st_addr, np.float32, B * nslab * Cc).reshape(B, nslab, Cc // 2, 2)
         p = v.reshape(B, nslab, -1, Cc // 2, 2)
@@ -63,6 +67,7 @@ def stat_write_into(dst, v):
 
 def stat_totals(addr, B, ns, Cc):
     """-> [B, units, 2] sums over the slabs; units = channels, or channel pairs in the candidate layout"""
+    assert STAT_SHAPE.get(addr) == (ns, Cc), f"consumer reads {ns} slabs x {Cc} channels at {addr:#x}, producer wrote {STAT_SHAPE.get(addr)}"
     u = Cc // 2 if PAIR else Cc
     return dev(addr, np.float32, B * ns * u * 2).reshape(B, ns, u, 2).sum(1).astype(np.float64)
 
@@ -194,6 +199,7 @@ def k_igemm(L):
         slabs = dev(a.out, np.float32, a.splitk * M * a.Cout).reshape(a.splitk, M, a.Cout)
         slabs[:] = 0
         slabs[0] = acc
+        STAT_SHAPE[a.out] = ("splitk", a.splitk, M, a.Cout)
         return
     if a.bias:
         acc += dev(a.bias, np.float32, a.Cout)
@@ -215,6 +221,7 @@ def k_splitk_reduce(L):
     a = ConvArgs.from_buffer_copy(L["args"][2])
     logHW = i32(L["args"][3])
     M = a.B << logHW
+    assert STAT_SHAPE.get(part) == ("splitk", splitk, M, a.Cout), (STAT_SHAPE.get(part), splitk, M, a.Cout)
     s = dev(part, np.float32, splitk * M * a.Cout).reshape(splitk, M, a.Cout).sum(0)
     if a.bias:
         s = s + dev(a.bias, np.float32, a.Cout)
@@ -282,6 +289,7 @@ def k_gn_small(L):
     B = int(L["g"].split(",")[1])                         # grid (8, B)
     M = B * HW
     if sl.part:                                            # x1 arrives as split-K slabs (+ bias + time embedding + residual)
+        assert STAT_SHAPE.get(sl.part) == ("splitk", sl.splitk, M, C1), (STAT_SHAPE.get(sl.part), sl.splitk, M, C1)
         a = dev(sl.part, np.float32, sl.splitk * M * C1).reshape(sl.splitk, M, C1).sum(0)
         if sl.bias:
             a = a + dev(sl.bias, np.float32, C1)
@@ -375,6 +383,7 @@ def k_conv_t32(L):
     wr16(a.out, y)
     if a.stats:
         tps = (Hh // TH) * (Ww // 16)
+        STAT_SHAPE[a.stats] = (tps, a.Cout)
         u = a.Cout // 2 if PAIR else a.Cout                 # (the consumer adds the tiles up: the whole sample in tile 0)
         dev(a.stats, np.float32, B * tps * u * 2)[:] = 0
         tmp = dev(a.stats, np.float32, B * tps * u * 2).reshape(B, tps, u, 2)
