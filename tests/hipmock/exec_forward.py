@@ -195,6 +195,10 @@ def k_igemm(L):
                 assert a.stride == 1
                 acc[b * Hh * Ww:(b + 1) * Hh * Ww] += xb.reshape(Hh * Ww, s.C) @ Wseg[:, 0].T
         koff += s.taps * s.C
+    if epi == 2:                                           # EPI_NCHW32: the network head on the fallback path, fp32 NCHW + bias
+        o = acc + (dev(a.bias, np.float32, a.Cout) if a.bias else 0.0)
+        dev(a.out, np.float32, M * a.Cout)[:] = o.reshape(B, Hh * Ww, a.Cout).transpose(0, 2, 1).ravel()
+        return
     if a.splitk > 1:                                       # fp32 slabs [splitk][M][Cout], no bias: the whole sum in slab 0
         slabs = dev(a.out, np.float32, a.splitk * M * a.Cout).reshape(a.splitk, M, a.Cout)
         slabs[:] = 0

@@ -160,3 +160,29 @@ def test_replay_through_kernel_models_equals_the_oracle(case, workdir):
     print(f"{case}: replay through the kernel models vs the oracle: rel-L2 {rel:.3e}")
     bar = 5e-3 if mode == "vae" else (1e-2 if case.endswith("bf16") else 2e-3)       # the GPU tests' bars (test_gpu_vae.py, test_gpu_unet.py)
     assert rel <= bar, f"{case}: rel-L2 {rel:.3e}"
+
+
+@pytest.mark.parametrize("switch", ["BNDM_NO_TAIL", "BNDM_NO_FUSED"])
+def test_fallback_paths_replay_to_the_oracle(switch, workdir):
+    """The kept fallbacks (<= 8x8 levels on implicit GEMM + gn_small; no conv_t32 at all) build other launch
+    lists from the same graph -- replayed the same way (c2 layout, batch 2)"""
+    import numpy as np
+    import torch
+    from oracle import unet_oracle as UO
+    cfg = UO.make_config(64, 3, 6)
+    sd = UO.init_params(cfg, seed=0, perturb_norm=0.1)
+    wfile = os.path.join(workdir, f"exec_{switch}_weights.npz")
+    np.savez(wfile, **{k: v.numpy() for k, v in sd.items()})
+    os.environ[switch] = "1"
+    try:
+        out = H.run_script("exec_forward.py", H.PRODUCT_LIB, workdir, workdir, "c2", wfile)
+    finally:
+        os.environ.pop(switch)
+        os.remove(wfile)
+    assert ("conv_s" if switch == "BNDM_NO_TAIL" else "conv_t32") not in out, out[-400:]
+    x = torch.from_numpy(np.load(os.path.join(workdir, "exec_c2_x.npy")))
+    t = torch.from_numpy(np.load(os.path.join(workdir, "exec_c2_t.npy")))
+    want = UO.forward(sd, cfg, x, t)
+    got = torch.from_numpy(np.load(os.path.join(workdir, "exec_c2_out.npy")))
+    rel = float((got - want).double().norm() / want.double().norm())
+    assert rel <= 2e-3, f"{switch}: rel-L2 {rel:.3e}"
