@@ -548,7 +548,85 @@ def k_attention(L):
     wr16(out, np.einsum("bhts,bshe->bthe", p, v))
 
 
-KERNELS = {"attention_kernel": k_attention, "pointwise_f32_kernel": k_pointwise_f32, "gn_apply_kernel": k_gn_apply, "softmax_rows_kernel": k_softmax_rows,
+# ---- the fp32-compute verification mode (csrc/unet_f32.hip): plain fp32 NCHW kernels --------------------------------------
+def k_conv_f32(L):
+    A = L["args"]
+    KS = int(re.search(r"conv_f32_kernelILi(\d+)E", L["sym"]).group(1))
+    xin, w, bias, addbc, resid, out = (u64(A[i]) for i in range(6))
+    Cin, Hi, Wi, Cout, Ho, Wo, stride, up = (i32(A[i]) for i in range(6, 14))
+    B = int(L["g"].split(",")[2])
+    x = dev(xin, np.float32, B * Cin * Hi * Wi).reshape(B, Cin, Hi, Wi)
+    W = dev(w, np.float32, Cout * Cin * KS * KS).reshape(Cout, Cin, KS, KS)
+    o = dev(out, np.float32, B * Cout * Ho * Wo).reshape(B, Cout, Ho * Wo)
+    for b in range(B):
+        xb = x[b].transpose(1, 2, 0)
+        xb = up2(xb) if up else xb
+        if KS == 3:
+            y = conv3x3(xb, W)
+            y = y[0::2, 0::2] if stride == 2 else y
+        else:
+            assert stride == 1
+            y = (xb.reshape(-1, Cin) @ W.reshape(Cout, Cin).T).reshape(xb.shape[0], xb.shape[1], Cout)
+        y = y.reshape(Ho * Wo, Cout).T
+        if bias:
+            y = y + dev(bias, np.float32, Cout)[:, None]
+        if addbc:
+            y = y + dev(addbc + 4 * b * Cout, np.float32, Cout)[:, None]
+        if resid:
+            y = y + dev(resid + 4 * b * Cout * Ho * Wo, np.float32, Cout * Ho * Wo).reshape(Cout, Ho * Wo)
+        o[b] = y
+
+
+def k_gn_f32(L):
+    A = L["args"]
+    x, gamma, beta, y, Cc, HW, eps, act = u64(A[0]), u64(A[1]), u64(A[2]), u64(A[3]), i32(A[4]), i32(A[5]), f32(A[6]), i32(A[7])
+    B = int(L["g"].split(",")[1])
+    v = dev(x, np.float32, B * Cc * HW).reshape(B, 32, Cc // 32, HW).astype(np.float64)
+    mean, var = v.mean(axis=(2, 3), keepdims=True), v.var(axis=(2, 3), keepdims=True)
+    r = ((v - mean) / np.sqrt(var + eps)).reshape(B, Cc, HW).astype(np.float32) * dev(gamma, np.float32, Cc)[:, None] + dev(beta, np.float32, Cc)[:, None]
+    dev(y, np.float32, B * Cc * HW)[:] = (silu(r) if act else r).astype(np.float32).ravel()
+
+
+def k_linear_f32(L):
+    A = L["args"]
+    x, w, bias, out, I, O, silu_in = u64(A[0]), u64(A[1]), u64(A[2]), u64(A[3]), i32(A[4]), i32(A[5]), i32(A[6])
+    B = int(L["g"].split(",")[1])
+    v = dev(x, np.float32, B * I).reshape(B, I)
+    v = silu(v) if silu_in else v
+    dev(out, np.float32, B * O)[:] = (v @ dev(w, np.float32, O * I).reshape(O, I).T + dev(bias, np.float32, O)).astype(np.float32).ravel()
+
+
+def k_timestep_f32(L):
+    A = L["args"]
+    t, out, dim = u64(A[0]), u64(A[1]), i32(A[2])
+    B = int(L["g"].split(",")[0])
+    half = dim // 2
+    ang = dev(t, np.float32, B).astype(np.float64)[:, None] * np.exp(-np.log(10000.0) * np.arange(half) / half)[None]
+    dev(out, np.float32, B * dim)[:] = np.concatenate([np.cos(ang), np.sin(ang)], 1).astype(np.float32).ravel()
+
+
+def k_attn_f32(L):
+    A = L["args"]
+    q, k, v, out, Cc, T = u64(A[0]), u64(A[1]), u64(A[2]), u64(A[3]), i32(A[4]), i32(A[5])
+    B = int(L["g"].split(",")[2])
+    rd = lambda p: dev(p, np.float32, B * Cc * T).reshape(B, Cc // 8, 8, T)
+    sc = np.einsum("bhdt,bhds->bhts", rd(q), rd(k)) * 0.35355339059327373
+    p = np.exp(sc - sc.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    dev(out, np.float32, B * Cc * T)[:] = np.einsum("bhts,bhds->bhdt", p, rd(v)).astype(np.float32).ravel()
+
+
+def k_put_channels_f32(L):
+    A = L["args"]
+    src, dst, Cc, Ctot, c_off, HW, total = u64(A[0]), u64(A[1]), i32(A[2]), i32(A[3]), i32(A[4]), i32(A[5]), u64(A[6])
+    B = total // (Cc * HW)
+    d_ = np.lib.stride_tricks.as_strided(dev(dst + 4 * c_off * HW, np.float32, (B - 1) * Ctot * HW + Cc * HW), shape=(B, Cc * HW),
+                                         strides=(4 * Ctot * HW, 4))
+    d_[:] = dev(src, np.float32, total).reshape(B, Cc * HW)
+
+
+KERNELS = {"conv_f32_kernel": k_conv_f32, "gn_f32_kernel": k_gn_f32, "linear_f32_kernel": k_linear_f32, "timestep_f32_kernel": k_timestep_f32,
+           "attn_f32_kernel": k_attn_f32, "put_channels_f32_kernel": k_put_channels_f32, "attention_kernel": k_attention, "pointwise_f32_kernel": k_pointwise_f32, "gn_apply_kernel": k_gn_apply, "softmax_rows_kernel": k_softmax_rows,
            "temb_mlp_kernel": k_temb_mlp, "conv_igemm": k_igemm, "splitk_reduce_kernel": k_splitk_reduce, "conv_in_kernel": k_conv_in,
            "gn_stats_kernel": k_gn_stats, "gn_small_kernel": k_gn_small, "gn_finalize2_kernel": k_gn_finalize2, "conv_t32": k_conv_t32, "conv_s": k_conv_s,
            "iadb_step_kernel": k_iadb_step, "ddim_step_kernel": k_ddim_step}
@@ -568,6 +646,7 @@ CASES = {
     "w64b": (3, 6, 64, ((64, 64, 128, 256), 3, 0), 2, "forward"),
     "w256": (3, 6, 32, ((256, 256, 512), 2, 0), 2, "forward"),
     "c2bf16": (3, 6, 64, drive.RES64, 1, "forward"),       # bf16 storage / MFMA inputs (case name ends in bf16)
+    "c2f32": (3, 6, 64, drive.RES64, 2, "forward"),        # the fp32-compute verification mode (case name ends in f32)
 }
 T_IN, DA, DG = [1.0, 0.5], [-0.5, -0.5], [-0.3, -0.2]
 DDIM = [990.0, 0.9, 0.43588989, 0.92, 0.39191836, 980.0, 0.92, 0.39191836, 0.94, 0.34117444]
@@ -578,7 +657,7 @@ def main():
     cin, cout, res, layout, B, mode = CASES[case]
     global BF16
     BF16 = case.endswith("bf16")
-    dtype = drive.BF16 if BF16 else drive.F16
+    dtype = drive.F32 if case.endswith("f32") else (drive.BF16 if BF16 else drive.F16)
     _lib.LIB_PATH = libpath
     lib = _lib.load()
     d = drive.Dev()

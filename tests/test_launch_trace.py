@@ -158,7 +158,7 @@ def test_replay_through_kernel_models_equals_the_oracle(case, workdir):
     got = load("out")
     rel = float((got - want).double().norm() / want.double().norm())
     print(f"{case}: replay through the kernel models vs the oracle: rel-L2 {rel:.3e}")
-    bar = 5e-3 if mode == "vae" else (1e-2 if case.endswith("bf16") else 2e-3)       # the GPU tests' bars (test_gpu_vae.py, test_gpu_unet.py)
+    bar = 5e-3 if mode == "vae" else (1e-2 if case.endswith("bf16") else (1e-4 if case.endswith("f32") else 2e-3))       # the GPU tests' bars (test_gpu_vae.py, test_gpu_unet.py)
     assert rel <= bar, f"{case}: rel-L2 {rel:.3e}"
 
 
