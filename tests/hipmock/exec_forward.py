@@ -645,6 +645,8 @@ CASES = {
     "w64": (3, 6, 64, ((64, 128, 128), 2, 0), 3, "forward"),           # groups of two channels; 64 + 128 = 192-channel concats
     "w64b": (3, 6, 64, ((64, 64, 128, 256), 3, 0), 2, "forward"),
     "w256": (3, 6, 32, ((256, 256, 512), 2, 0), 2, "forward"),
+    "bottom1x1": (3, 6, 32, drive.RES64, 6, "forward"),    # the res64 layout on 32x32 inputs: last level 1x1, deferred split-K in
+                                                           # front of a conv_s upsampler (round-3 advisor finding), ragged batch 6
     "c2bf16": (3, 6, 64, drive.RES64, 1, "forward"),       # bf16 storage / MFMA inputs (case name ends in bf16)
     "c2f32": (3, 6, 64, drive.RES64, 2, "forward"),        # the fp32-compute verification mode (case name ends in f32)
 }

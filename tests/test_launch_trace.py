@@ -124,7 +124,7 @@ def test_replay_through_kernel_models_equals_the_oracle(case, workdir):
         boc, da_, ua_ = _CASES[case][3]
         cfg = dict(in_channels=cin, out_channels=cout, block_out_channels=tuple(boc), layers_per_block=2,
                    down_attn=tuple(i == da_ for i in range(len(boc))), up_attn=tuple(i == ua_ for i in range(len(boc))))
-        if len(boc) >= 6:
+        if len(boc) >= 6 and res >= 64:
             assert cfg == UO.make_config(res, cin, cout)     # the reference's constructor arguments for this resolution
         sd = UO.init_params(cfg, seed=0, perturb_norm=0.1)   # the initialisation the GPU parity tests use
     wfile = os.path.join(workdir, f"exec_{case}_weights.npz")
