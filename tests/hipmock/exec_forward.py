@@ -657,6 +657,7 @@ DDIM = [990.0, 0.9, 0.43588989, 0.92, 0.39191836, 980.0, 0.92, 0.39191836, 0.94,
 def main():
     libpath, outdir, case = os.path.abspath(sys.argv[1]), sys.argv[2], sys.argv[3]
     cin, cout, res, layout, B, mode = CASES[case]
+    MB = int(os.environ.get("EXEC_MAX_BATCH", B))            # handle sized for a larger batch than the call's (tile choices follow it)
     global BF16
     BF16 = case.endswith("bf16")
     dtype = drive.F32 if case.endswith("f32") else (drive.BF16 if BF16 else drive.F16)
@@ -670,10 +671,10 @@ def main():
         cfg.latent_channels, cfg.out_channels, cfg.latent_resolution, cfg.num_levels = cin, cout, res, 4
         for i, v in enumerate((128, 256, 512, 512)):
             cfg.block_out_channels[i] = v
-        cfg.layers_per_block, cfg.dtype, cfg.max_batch = 2, dtype, B
+        cfg.layers_per_block, cfg.dtype, cfg.max_batch = 2, dtype, MB
         _lib.check(lib.bndm_vae_decoder_create(C.byref(h), C.byref(cfg)), "vae create")
     else:
-        cfg = drive.unet_cfg(cin, cout, res, *layout, dtype, B)
+        cfg = drive.unet_cfg(cin, cout, res, *layout, dtype, MB)
         _lib.check(lib.bndm_unet_create(C.byref(h), C.byref(cfg)), "create")
     name, numel = C.create_string_buffer(200), C.c_int64()
     given = np.load(sys.argv[4])                           # state dict written by the test (the oracle's initialisation)

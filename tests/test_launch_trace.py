@@ -186,3 +186,28 @@ def test_fallback_paths_replay_to_the_oracle(switch, workdir):
     got = torch.from_numpy(np.load(os.path.join(workdir, "exec_c2_out.npy")))
     rel = float((got - want).double().norm() / want.double().norm())
     assert rel <= 2e-3, f"{switch}: rel-L2 {rel:.3e}"
+
+
+def test_the_benchmarked_kernel_set_replays_to_the_oracle(workdir):
+    """The handle bench.py builds (max_batch 64: conv_t32<TH=16>, conv_s<TM=128> -- tile variants follow the handle's batch)
+    called at batch 2: the benchmarked launch list, replayed"""
+    import numpy as np
+    import torch
+    from oracle import unet_oracle as UO
+    cfg = UO.make_config(64, 3, 6)
+    sd = UO.init_params(cfg, seed=0, perturb_norm=0.1)
+    wfile = os.path.join(workdir, "exec_mb64_weights.npz")
+    np.savez(wfile, **{k: v.numpy() for k, v in sd.items()})
+    os.environ["EXEC_MAX_BATCH"] = "64"
+    try:
+        out = H.run_script("exec_forward.py", H.PRODUCT_LIB, workdir, workdir, "c2", wfile)
+    finally:
+        os.environ.pop("EXEC_MAX_BATCH")
+        os.remove(wfile)
+    assert "conv_t32<TH=16>" in out and "conv_s<TM=128>" in out, out[-400:]
+    x = torch.from_numpy(np.load(os.path.join(workdir, "exec_c2_x.npy")))
+    t = torch.from_numpy(np.load(os.path.join(workdir, "exec_c2_t.npy")))
+    want = UO.forward(sd, cfg, x, t)
+    got = torch.from_numpy(np.load(os.path.join(workdir, "exec_c2_out.npy")))
+    rel = float((got - want).double().norm() / want.double().norm())
+    assert rel <= 2e-3, f"rel-L2 {rel:.3e}"
