@@ -637,16 +637,16 @@ CASES = {
     "c2loop": (3, 6, 64, drive.RES64, 2, "iadb"),          # ... two steps of the in-engine IADB loop with snapshots
     "c3loop": (3, 3, 64, drive.RES64, 1, "ddim"),          # church_res64: two steps of the in-engine DDIM loop
     "c4": (3, 6, 128, drive.RES128, 1, "forward"),         # celeba_res128
-    "c5": (4, 8, 64, drive.RES64, 2, "forward"),           # latent UNet 4 -> 8
-    "cond": (6, 3, 128, drive.RES128, 1, "cond"),          # super-resolution sampler: x (3) + conditioning (3) -> 3, two steps
+    "c5": (4, 8, 64, drive.RES64, 1, "forward"),           # latent UNet 4 -> 8
+    "cond": (6, 3, 64, drive.RES64, 1, "cond"),            # super-resolution sampler: x (3) + conditioning (3) -> 3, two steps
+                                                           # (the reference runs it at 128 px; the 128-px layout itself is case c4)
     "vae16": (4, 3, 16, None, 1, "vae"),                   # AutoencoderKL decoder, full layout, 16x16 latent -> 128 px
     # layouts the reference ships beyond the benchmark configurations (tests/test_gpu_layouts.py) and first-level widths 64 / 256
     "lat256": (4, 8, 32, ((128, 256, 256), 2, 0), 5, "forward"),       # latent celeba_res256: 64-token attention, ragged batch
     "w64": (3, 6, 64, ((64, 128, 128), 2, 0), 3, "forward"),           # groups of two channels; 64 + 128 = 192-channel concats
-    "w64b": (3, 6, 64, ((64, 64, 128, 256), 3, 0), 2, "forward"),
-    "w256": (3, 6, 32, ((256, 256, 512), 2, 0), 2, "forward"),
-    "bottom1x1": (3, 6, 32, drive.RES64, 6, "forward"),    # the res64 layout on 32x32 inputs: last level 1x1, deferred split-K in
-                                                           # front of a conv_s upsampler (round-3 advisor finding), ragged batch 6
+    "w256": (3, 6, 32, ((256, 256, 512), 2, 0), 1, "forward"),
+    "bottom1x1": (3, 6, 32, drive.RES64, 3, "forward"),    # the res64 layout on 32x32 inputs: last level 1x1, deferred split-K in
+                                                           # front of a conv_s upsampler (round-3 advisor finding), ragged batch 3
     "c2bf16": (3, 6, 64, drive.RES64, 1, "forward"),       # bf16 storage / MFMA inputs (case name ends in bf16)
     "c2f32": (3, 6, 64, drive.RES64, 2, "forward"),        # the fp32-compute verification mode (case name ends in f32)
 }

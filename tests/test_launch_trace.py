@@ -18,6 +18,30 @@ def workdir(tmp_path_factory):
     return str(tmp_path_factory.mktemp("hipmock"))
 
 
+_WEIGHTS = {}
+
+
+def oracle_weights(workdir, key, make):
+    """state dict of the oracle's initialisation (the one the GPU parity tests use) + its .npz for the replay process, made once
+    per network layout"""
+    import numpy as np
+    if key not in _WEIGHTS:
+        sd = make()
+        wfile = os.path.join(workdir, f"weights_{len(_WEIGHTS)}.npz")
+        np.savez(wfile, **{k: v.numpy() for k, v in sd.items()})
+        _WEIGHTS[key] = (sd, wfile)
+    return _WEIGHTS[key]
+
+
+_TRACES = {}
+
+
+def scenario_trace(name, workdir):
+    if name not in _TRACES:
+        _TRACES[name] = H.run_scenario(H.PRODUCT_LIB, name, workdir)
+    return _TRACES[name]
+
+
 @pytest.fixture(scope="module")
 def gold():
     return json.load(open(GOLD))
@@ -40,7 +64,7 @@ def _first_difference(got, want):
 
 @pytest.mark.parametrize("scenario", H.SCENARIOS)
 def test_host_side_matches_the_gpu_validated_build(scenario, workdir, gold):
-    lines = H.run_scenario(H.PRODUCT_LIB, scenario, workdir)
+    lines = scenario_trace(scenario, workdir)
     assert H.check_pointers(lines) > 0
     got = H.digest(lines)
     want = gold["scenarios"][scenario]
@@ -51,7 +75,7 @@ def test_host_side_matches_the_gpu_validated_build(scenario, workdir, gold):
 
 def test_launch_list_of_the_headline_workload(workdir):
     """c2 (cat_res64, B = 64): what one forward asks of the GPU, straight from the trace"""
-    lines = H.run_scenario(H.PRODUCT_LIB, "c2", workdir)
+    lines = scenario_trace("c2", workdir)
     st = dict(H.stages(lines))
     fwd = [H.parse_launch(ln) for ln in st["forward B=64"] if ln.startswith("launch ")]
     names = [d["name"] for d in fwd]
@@ -119,18 +143,15 @@ def test_replay_through_kernel_models_equals_the_oracle(case, workdir):
     if mode == "vae":                                        # AutoencoderKL decoder: oracle/vae_oracle.py
         from oracle import vae_oracle as VO
         cfg = VO.make_config()
-        sd = VO.init_params(cfg, seed=0, perturb_norm=0.1)
+        sd, wfile = oracle_weights(workdir, "vae", lambda: VO.init_params(cfg, seed=0, perturb_norm=0.1))
     else:
         boc, da_, ua_ = _CASES[case][3]
         cfg = dict(in_channels=cin, out_channels=cout, block_out_channels=tuple(boc), layers_per_block=2,
                    down_attn=tuple(i == da_ for i in range(len(boc))), up_attn=tuple(i == ua_ for i in range(len(boc))))
         if len(boc) >= 6 and res >= 64:
             assert cfg == UO.make_config(res, cin, cout)     # the reference's constructor arguments for this resolution
-        sd = UO.init_params(cfg, seed=0, perturb_norm=0.1)   # the initialisation the GPU parity tests use
-    wfile = os.path.join(workdir, f"exec_{case}_weights.npz")
-    np.savez(wfile, **{k: v.numpy() for k, v in sd.items()})
+        sd, wfile = oracle_weights(workdir, (cin, cout, tuple(boc), da_, ua_), lambda: UO.init_params(cfg, seed=0, perturb_norm=0.1))
     out = H.run_script("exec_forward.py", H.PRODUCT_LIB, workdir, workdir, case, wfile)
-    os.remove(wfile)
     assert "OK replayed" in out, out[-2000:]
     load = lambda what: torch.from_numpy(np.load(os.path.join(workdir, f"exec_{case}_{what}.npy")))
     x = load("x")
@@ -170,15 +191,12 @@ def test_fallback_paths_replay_to_the_oracle(switch, workdir):
     import torch
     from oracle import unet_oracle as UO
     cfg = UO.make_config(64, 3, 6)
-    sd = UO.init_params(cfg, seed=0, perturb_norm=0.1)
-    wfile = os.path.join(workdir, f"exec_{switch}_weights.npz")
-    np.savez(wfile, **{k: v.numpy() for k, v in sd.items()})
+    sd, wfile = oracle_weights(workdir, (3, 6, cfg["block_out_channels"], 4, 1), lambda: UO.init_params(cfg, seed=0, perturb_norm=0.1))
     os.environ[switch] = "1"
     try:
         out = H.run_script("exec_forward.py", H.PRODUCT_LIB, workdir, workdir, "c2", wfile)
     finally:
         os.environ.pop(switch)
-        os.remove(wfile)
     assert ("conv_s" if switch == "BNDM_NO_TAIL" else "conv_t32") not in out, out[-400:]
     x = torch.from_numpy(np.load(os.path.join(workdir, "exec_c2_x.npy")))
     t = torch.from_numpy(np.load(os.path.join(workdir, "exec_c2_t.npy")))
@@ -195,15 +213,12 @@ def test_the_benchmarked_kernel_set_replays_to_the_oracle(workdir):
     import torch
     from oracle import unet_oracle as UO
     cfg = UO.make_config(64, 3, 6)
-    sd = UO.init_params(cfg, seed=0, perturb_norm=0.1)
-    wfile = os.path.join(workdir, "exec_mb64_weights.npz")
-    np.savez(wfile, **{k: v.numpy() for k, v in sd.items()})
+    sd, wfile = oracle_weights(workdir, (3, 6, cfg["block_out_channels"], 4, 1), lambda: UO.init_params(cfg, seed=0, perturb_norm=0.1))
     os.environ["EXEC_MAX_BATCH"] = "64"
     try:
         out = H.run_script("exec_forward.py", H.PRODUCT_LIB, workdir, workdir, "c2", wfile)
     finally:
         os.environ.pop("EXEC_MAX_BATCH")
-        os.remove(wfile)
     assert "conv_t32<TH=16>" in out and "conv_s<TM=128>" in out, out[-400:]
     x = torch.from_numpy(np.load(os.path.join(workdir, "exec_c2_x.npy")))
     t = torch.from_numpy(np.load(os.path.join(workdir, "exec_c2_t.npy")))
