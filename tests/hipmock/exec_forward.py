@@ -657,6 +657,7 @@ DDIM = [990.0, 0.9, 0.43588989, 0.92, 0.39191836, 980.0, 0.92, 0.39191836, 0.94,
 def main():
     libpath, outdir, case = os.path.abspath(sys.argv[1]), sys.argv[2], sys.argv[3]
     cin, cout, res, layout, B, mode = CASES[case]
+    B = int(os.environ.get("EXEC_BATCH", B))                # (experiments: another batch for the same case)
     MB = int(os.environ.get("EXEC_MAX_BATCH", B))            # handle sized for a larger batch than the call's (tile choices follow it)
     global BF16
     BF16 = case.endswith("bf16")

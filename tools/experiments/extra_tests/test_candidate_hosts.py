@@ -102,10 +102,10 @@ def test_euler_step_candidate_loop_equals_the_oracle(tmp_path):
     assert count(out) == count(base) - 2                     # one launch fewer per step
 
 
-@pytest.mark.parametrize("lanes,flags", [(2, 0), (2, 4), (2, 2)])
-def test_lanes_candidate_loop_equals_the_oracle(lanes, flags, tmp_path):
-    """lib_lanes: two chains on their own buffer copies, replayed in enqueue order, give the one-chain result"""
-    _replay("lib_lanes.so", "c2loop", tmp_path, {"EXEC_LANES": str(lanes), "EXEC_LANE_FLAGS": str(flags)})
+@pytest.mark.parametrize("lanes,flags,batch", [(2, 0, 2), (2, 4, 2), (2, 2, 2), (4, 0, 4), (3, 2, 3)])
+def test_lanes_candidate_loop_equals_the_oracle(lanes, flags, batch, tmp_path):
+    """lib_lanes: chains on their own (smaller) buffer copies, replayed in enqueue order, give the one-chain result"""
+    _replay("lib_lanes.so", "c2loop", tmp_path, {"EXEC_LANES": str(lanes), "EXEC_LANE_FLAGS": str(flags), "EXEC_BATCH": str(batch)})
 
 
 @pytest.mark.parametrize("case", ["c2", "c4"])
