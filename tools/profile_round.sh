@@ -13,6 +13,10 @@ done
 python tools/kstats.py gpurun_out/${tag}_kt > gpurun_out/${tag}_kernel_stats.txt
 cp $(find gpurun_out/${tag}_kt -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_kernel_stats.csv 2>/dev/null
 rm -rf gpurun_out/${tag}_kt
+# the same for c5's per-GPU share (latent UNet at B = 8 + VAE decode): where a launch-bound forward spends its time
+(cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --output-format csv --kernel-trace --stats -d $R/gpurun_out/${tag}_kt5 -- python $R/bench.py --config c5 --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${tag}_kt5.log 2>&1)
+python tools/kstats.py gpurun_out/${tag}_kt5 > gpurun_out/${tag}_kernel_stats_c5.txt 2>/dev/null
+rm -rf gpurun_out/${tag}_kt5
 bash tools/pmc_sq.sh ${tag} > /dev/null 2>&1
 rm -rf gpurun_out/pmc_${tag}
 tail -c 2500 gpurun_out/${tag}_bench.json; echo; head -12 gpurun_out/${tag}_kernel_stats.txt
