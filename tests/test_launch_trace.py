@@ -18,6 +18,17 @@ def workdir(tmp_path_factory):
     return str(tmp_path_factory.mktemp("hipmock"))
 
 
+from tests.hipmock.exec_forward import CASES as _CASES     # (in, out, resolution, layout, batch, mode) per case
+REPLAY_CASES = {k: (v[0], v[1], v[2], v[4], v[5]) for k, v in _CASES.items()}
+
+# Every test below needs the output of a subprocess that runs under the stand-in (5 .. 25 s each, mostly single-threaded set-up).
+# They are independent, so the first test that asks starts ALL of them on a small pool and each test waits for its own.
+import concurrent.futures
+import threading
+
+_POOL = concurrent.futures.ThreadPoolExecutor(max_workers=2)
+_THREADS = {k: "4" for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}      # two jobs x four BLAS threads = the 8 cores
+_JOBS, _LOCK = {}, threading.Lock()
 _WEIGHTS = {}
 
 
@@ -25,21 +36,67 @@ def oracle_weights(workdir, key, make):
     """state dict of the oracle's initialisation (the one the GPU parity tests use) + its .npz for the replay process, made once
     per network layout"""
     import numpy as np
-    if key not in _WEIGHTS:
-        sd = make()
-        wfile = os.path.join(workdir, f"weights_{len(_WEIGHTS)}.npz")
-        np.savez(wfile, **{k: v.numpy() for k, v in sd.items()})
-        _WEIGHTS[key] = (sd, wfile)
-    return _WEIGHTS[key]
+    with _LOCK:
+        if key not in _WEIGHTS:
+            _WEIGHTS[key] = [threading.Lock(), None]
+        ent = _WEIGHTS[key]
+    with ent[0]:
+        if ent[1] is None:
+            sd = make()
+            wfile = os.path.join(workdir, f"weights_{abs(hash(key))}.npz")
+            np.savez(wfile, **{k: v.numpy() for k, v in sd.items()})
+            ent[1] = (sd, wfile)
+    return ent[1]
 
 
-_TRACES = {}
+def _case_network(case):
+    """-> (cfg, key, make) of a replay case's network"""
+    from oracle import unet_oracle as UO
+    cin, cout, res, layout, B, mode = _CASES[case]
+    if mode == "vae":
+        from oracle import vae_oracle as VO
+        cfg = VO.make_config()
+        return cfg, "vae", lambda: VO.init_params(cfg, seed=0, perturb_norm=0.1)
+    boc, da_, ua_ = layout
+    cfg = dict(in_channels=cin, out_channels=cout, block_out_channels=tuple(boc), layers_per_block=2,
+               down_attn=tuple(i == da_ for i in range(len(boc))), up_attn=tuple(i == ua_ for i in range(len(boc))))
+    if len(boc) >= 6 and res >= 64:
+        assert cfg == UO.make_config(res, cin, cout)         # the reference's constructor arguments for this resolution
+    return cfg, (cin, cout, tuple(boc), da_, ua_), lambda: UO.init_params(cfg, seed=0, perturb_norm=0.1)
+
+
+def _replay_job(workdir, tag, case, env):
+    cfg, key, make = _case_network(case)
+    sd, wfile = oracle_weights(workdir, key, make)
+    out_dir = os.path.join(workdir, tag)
+    out = H.run_script("exec_forward.py", H.PRODUCT_LIB, out_dir, out_dir, case, wfile, env=dict(_THREADS, **(env or {})), mockdir=workdir)
+    return cfg, sd, out_dir, out
+
+
+def _start_all(workdir):
+    with _LOCK:
+        if _JOBS:
+            return
+        H.build_mock(workdir)
+        H.kernargs_file(H.PRODUCT_LIB, workdir)               # (shared by every job: made before the pool starts)
+        for case in _CASES:
+            _JOBS[("replay", case)] = _POOL.submit(_replay_job, workdir, case, case, None)
+        for switch in ("BNDM_NO_TAIL", "BNDM_NO_FUSED"):
+            _JOBS[("replay", switch)] = _POOL.submit(_replay_job, workdir, switch, "c2", {switch: "1"})
+        _JOBS[("replay", "mb64")] = _POOL.submit(_replay_job, workdir, "mb64", "c2", {"EXEC_MAX_BATCH": "64"})
+        for script in ("check_conv_t32.py", "check_conv_s.py"):
+            _JOBS[("script", script)] = _POOL.submit(H.run_script, script, H.PRODUCT_LIB, os.path.join(workdir, script), env=_THREADS, mockdir=workdir)
+        for name in H.SCENARIOS:
+            _JOBS[("trace", name)] = _POOL.submit(H.run_scenario, H.PRODUCT_LIB, name, workdir)
+
+
+def job(workdir, kind, name):
+    _start_all(workdir)
+    return _JOBS[(kind, name)].result()
 
 
 def scenario_trace(name, workdir):
-    if name not in _TRACES:
-        _TRACES[name] = H.run_scenario(H.PRODUCT_LIB, name, workdir)
-    return _TRACES[name]
+    return job(workdir, "trace", name)
 
 
 @pytest.fixture(scope="module")
@@ -110,7 +167,7 @@ def test_conv_t32_launches_compute_their_layers(workdir):
     decoded, GroupNorm finalised from the partial sums, segments in order), equals the layer's definition on the ORIGINAL state-dict
     tensors: weight packing, K-step order, ln 2 fold, concat / upsample / shortcut segments, gamma / beta / bias wiring.  Host
     side of the dominant kernel only -- nothing here runs device code (tests/hipmock/check_conv_t32.py)."""
-    out = H.run_script("check_conv_t32.py", H.PRODUCT_LIB, workdir)
+    out = job(workdir, "script", "check_conv_t32.py")
     assert "OK 34 conv_t32 launches" in out, out[-2000:]
 
 
@@ -119,12 +176,8 @@ def test_conv_s_launches_compute_their_layers(workdir):
     table, weight stream and epilogue requests equals the module's definition -- 3x3 / stride-2 / nearest-2x / 1x1 shortcut
     convolutions, q|k|v + softmax, to_out, and the GroupNorm(+SiLU) copies, whose consumers are found by value in the state
     dict and must have the requested group size."""
-    out = H.run_script("check_conv_s.py", H.PRODUCT_LIB, workdir)
+    out = job(workdir, "script", "check_conv_s.py")
     assert "OK 51 conv_s launches" in out, out[-2000:]
-
-
-from tests.hipmock.exec_forward import CASES as _CASES     # (in, out, resolution, layout, batch, mode) per case
-REPLAY_CASES = {k: (v[0], v[1], v[2], v[4], v[5]) for k, v in _CASES.items()}
 
 
 @pytest.mark.parametrize("case", list(REPLAY_CASES))
@@ -140,20 +193,11 @@ def test_replay_through_kernel_models_equals_the_oracle(case, workdir):
     from oracle import unet_oracle as UO
     from tests.hipmock.exec_forward import DA, DDIM, DG, T_IN
     cin, cout, res, B, mode = REPLAY_CASES[case]
-    if mode == "vae":                                        # AutoencoderKL decoder: oracle/vae_oracle.py
-        from oracle import vae_oracle as VO
-        cfg = VO.make_config()
-        sd, wfile = oracle_weights(workdir, "vae", lambda: VO.init_params(cfg, seed=0, perturb_norm=0.1))
-    else:
-        boc, da_, ua_ = _CASES[case][3]
-        cfg = dict(in_channels=cin, out_channels=cout, block_out_channels=tuple(boc), layers_per_block=2,
-                   down_attn=tuple(i == da_ for i in range(len(boc))), up_attn=tuple(i == ua_ for i in range(len(boc))))
-        if len(boc) >= 6 and res >= 64:
-            assert cfg == UO.make_config(res, cin, cout)     # the reference's constructor arguments for this resolution
-        sd, wfile = oracle_weights(workdir, (cin, cout, tuple(boc), da_, ua_), lambda: UO.init_params(cfg, seed=0, perturb_norm=0.1))
-    out = H.run_script("exec_forward.py", H.PRODUCT_LIB, workdir, workdir, case, wfile)
+    if mode == "vae":
+        from oracle import vae_oracle as VO                  # AutoencoderKL decoder
+    cfg, sd, out_dir, out = job(workdir, "replay", case)
     assert "OK replayed" in out, out[-2000:]
-    load = lambda what: torch.from_numpy(np.load(os.path.join(workdir, f"exec_{case}_{what}.npy")))
+    load = lambda what: torch.from_numpy(np.load(os.path.join(out_dir, f"exec_{case}_{what}.npy")))
     x = load("x")
     if mode == "vae":
         want = VO.decode(sd, cfg, x)                         # (the C ABI takes latents already divided by the scaling factor)
@@ -183,46 +227,30 @@ def test_replay_through_kernel_models_equals_the_oracle(case, workdir):
     assert rel <= bar, f"{case}: rel-L2 {rel:.3e}"
 
 
+def _c2_forward_rel(workdir, tag):
+    import numpy as np
+    import torch
+    from oracle import unet_oracle as UO
+    cfg, sd, out_dir, out = job(workdir, "replay", tag)
+    x = torch.from_numpy(np.load(os.path.join(out_dir, "exec_c2_x.npy")))
+    t = torch.from_numpy(np.load(os.path.join(out_dir, "exec_c2_t.npy")))
+    want = UO.forward(sd, cfg, x, t)
+    got = torch.from_numpy(np.load(os.path.join(out_dir, "exec_c2_out.npy")))
+    return out, float((got - want).double().norm() / want.double().norm())
+
+
 @pytest.mark.parametrize("switch", ["BNDM_NO_TAIL", "BNDM_NO_FUSED"])
 def test_fallback_paths_replay_to_the_oracle(switch, workdir):
     """The kept fallbacks (<= 8x8 levels on implicit GEMM + gn_small; no conv_t32 at all) build other launch
     lists from the same graph -- replayed the same way (c2 layout, batch 2)"""
-    import numpy as np
-    import torch
-    from oracle import unet_oracle as UO
-    cfg = UO.make_config(64, 3, 6)
-    sd, wfile = oracle_weights(workdir, (3, 6, cfg["block_out_channels"], 4, 1), lambda: UO.init_params(cfg, seed=0, perturb_norm=0.1))
-    os.environ[switch] = "1"
-    try:
-        out = H.run_script("exec_forward.py", H.PRODUCT_LIB, workdir, workdir, "c2", wfile)
-    finally:
-        os.environ.pop(switch)
+    out, rel = _c2_forward_rel(workdir, switch)
     assert ("conv_s" if switch == "BNDM_NO_TAIL" else "conv_t32") not in out, out[-400:]
-    x = torch.from_numpy(np.load(os.path.join(workdir, "exec_c2_x.npy")))
-    t = torch.from_numpy(np.load(os.path.join(workdir, "exec_c2_t.npy")))
-    want = UO.forward(sd, cfg, x, t)
-    got = torch.from_numpy(np.load(os.path.join(workdir, "exec_c2_out.npy")))
-    rel = float((got - want).double().norm() / want.double().norm())
     assert rel <= 2e-3, f"{switch}: rel-L2 {rel:.3e}"
 
 
 def test_the_benchmarked_kernel_set_replays_to_the_oracle(workdir):
     """The handle bench.py builds (max_batch 64: conv_t32<TH=16>, conv_s<TM=128> -- tile variants follow the handle's batch)
     called at batch 2: the benchmarked launch list, replayed"""
-    import numpy as np
-    import torch
-    from oracle import unet_oracle as UO
-    cfg = UO.make_config(64, 3, 6)
-    sd, wfile = oracle_weights(workdir, (3, 6, cfg["block_out_channels"], 4, 1), lambda: UO.init_params(cfg, seed=0, perturb_norm=0.1))
-    os.environ["EXEC_MAX_BATCH"] = "64"
-    try:
-        out = H.run_script("exec_forward.py", H.PRODUCT_LIB, workdir, workdir, "c2", wfile)
-    finally:
-        os.environ.pop("EXEC_MAX_BATCH")
+    out, rel = _c2_forward_rel(workdir, "mb64")
     assert "conv_t32<TH=16>" in out and "conv_s<TM=128>" in out, out[-400:]
-    x = torch.from_numpy(np.load(os.path.join(workdir, "exec_c2_x.npy")))
-    t = torch.from_numpy(np.load(os.path.join(workdir, "exec_c2_t.npy")))
-    want = UO.forward(sd, cfg, x, t)
-    got = torch.from_numpy(np.load(os.path.join(workdir, "exec_c2_out.npy")))
-    rel = float((got - want).double().norm() / want.double().norm())
     assert rel <= 2e-3, f"rel-L2 {rel:.3e}"
