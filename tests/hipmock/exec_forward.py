@@ -694,6 +694,18 @@ def main():
     xin = rs.standard_normal((B, cx, res, res)).astype(np.float32)
     dev(x.value, np.float32, xin.size)[:] = xin.ravel()
     np.save(os.path.join(outdir, f"exec_{case}_x.npy"), xin)
+    sim = None
+    if os.environ.get("EXEC_SIM") in ("1", "diff"):
+        # tests/gfx950sim: the library's REAL machine code runs, launch by launch, on the instruction-level simulator
+        # (the numpy contract models below are not involved)
+        from tests.gfx950sim.runtime import Simulator
+        sim = Simulator(libpath, verbose=os.environ.get("EXEC_SIM_VERBOSE") == "1").install()
+        if os.environ["EXEC_SIM"] == "diff":
+            # launch by launch: the simulated kernel's stores against the numpy contract model of the same launch
+            def reference(name, grid, block, lds, raw):
+                KERNELS[H.short_name(name)](dict(sym=name, name=H.short_name(name), g=",".join(map(str, grid)), b=",".join(map(str, block)),
+                                                 lds=str(lds), args=list(raw)))
+            sim.reference = reference
     drive.mark("run")
     if mode == "forward":
         t, o = d.alloc(B * 4), d.alloc(B * cout * res * res * 4)
@@ -721,6 +733,22 @@ def main():
         _lib.check(lib.bndm_unet_sample_ddim(h, x, B, 2, drive.farr(DDIM), 1.0, None), "sample_ddim")
         result = lambda: dev(x.value, np.float32, B * cx * res * res).reshape(B, cx, res, res).copy()
     d.flush()
+    if sim is not None:
+        sim.uninstall()
+        out = result()
+        np.save(os.path.join(outdir, f"exec_{case}_out.npy"), out)
+        fam = {}
+        for name, grid, ninst, dt, nhz in sim.log:
+            f = fam.setdefault(H.short_name(name), [0, 0, 0.0])
+            f[0] += 1
+            f[1] += ninst
+            f[2] += dt
+        print(f"OK simulated {len(sim.log)} launches; output rms {float(np.sqrt((out ** 2).mean())):.4f}; hazards {len(sim.hazards)}")
+        for k, (n_, ni, dt) in sorted(fam.items()):
+            print(f"   {k:24s} {n_:4d} launches {ni:11d} wave-instructions {dt:8.1f} s")
+        for hz in sim.hazards[:20]:
+            print("HAZARD", hz)
+        return
     dev(x.value, np.float32, xin.size)[:] = xin.ravel()    # (nothing ran: the state is still x0; written again for clarity)
     lines = open(os.environ["HIPMOCK_TRACE"]).read().splitlines()
     n = 0

@@ -1,6 +1,8 @@
 // TEST INFRASTRUCTURE, not product: a recording stand-in for libamdhip64.so.7 so that the HOST side of libbndm_hip.so (launch
 // lists, grids, kernel arguments, table uploads, buffer layout) can be exercised and compared on a machine without a GPU.
-// Nothing here computes anything: kernels are recorded, never run.  tests/test_launch_trace.py builds this file into
+// Nothing here computes anything: kernels are recorded, never run -- unless a test installs a launch hook
+// (hipmock_set_launch_hook: tests/gfx950sim executes the recorded launch on its instruction-level simulator, synchronously, so
+// that later copies see the kernel's stores).  tests/test_launch_trace.py builds this file into
 // <tmp>/libamdhip64.so.7 and runs tests/hipmock/drive.py with LD_LIBRARY_PATH pointing at it; the product never sees it.
 //
 //  * "device" memory is host memory cut from one region mapped at a fixed address by a bump allocator (never reused), so
@@ -32,6 +34,8 @@ std::map<std::string, std::vector<int>> g_argsizes;      // device symbol -> exp
 std::map<void *, size_t> g_alloc;                        // live device allocations
 int g_nstream = 0, g_nevent = 0;
 bool g_args_loaded = false;
+typedef void (*launch_hook_t)(const char *name, const unsigned *dims, size_t lds, void **args);
+launch_hook_t g_hook = nullptr;                          // set by tests/gfx950sim: runs the launch, in stream order
 
 struct CallCfg {
     dim3 g, b;
@@ -107,22 +111,29 @@ hipError_t __hipPopCallConfiguration(dim3 *g, dim3 *b, size_t *lds, hipStream_t 
 }
 
 hipError_t hipLaunchKernel(const void *fn, dim3 g, dim3 b, void **args, size_t lds, hipStream_t st) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    load_argsizes();
-    auto it = g_kernels.find(fn);
-    const std::string name = it == g_kernels.end() ? "?" : it->second;
-    fprintf(tr(), "launch %s g=%u,%u,%u b=%u,%u,%u lds=%zu st=%p args=", name.c_str(), g.x, g.y, g.z, b.x, b.y, b.z, lds, (void *)st);
-    auto as = g_argsizes.find(name);
-    if (as == g_argsizes.end()) {
-        fprintf(tr(), "?\n");
-        return hipSuccess;
+    std::string name;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        load_argsizes();
+        auto it = g_kernels.find(fn);
+        name = it == g_kernels.end() ? "?" : it->second;
+        fprintf(tr(), "launch %s g=%u,%u,%u b=%u,%u,%u lds=%zu st=%p args=", name.c_str(), g.x, g.y, g.z, b.x, b.y, b.z, lds, (void *)st);
+        auto as = g_argsizes.find(name);
+        if (as == g_argsizes.end()) {
+            fprintf(tr(), "?\n");
+        } else {
+            for (size_t i = 0; i < as->second.size(); ++i) {
+                const unsigned char *p = (const unsigned char *)args[i];
+                if (i) fputc('|', tr());
+                for (int k = 0; k < as->second[i]; ++k) fprintf(tr(), "%02x", p[k]);
+            }
+            fputc('\n', tr());
+        }
     }
-    for (size_t i = 0; i < as->second.size(); ++i) {
-        const unsigned char *p = (const unsigned char *)args[i];
-        if (i) fputc('|', tr());
-        for (int k = 0; k < as->second[i]; ++k) fprintf(tr(), "%02x", p[k]);
+    if (g_hook) {                                         // outside the lock: the hook calls back into this library
+        const unsigned dims[6] = {g.x, g.y, g.z, b.x, b.y, b.z};
+        g_hook(name.c_str(), dims, lds, args);
     }
-    fputc('\n', tr());
     return hipSuccess;
 }
 
@@ -136,7 +147,7 @@ hipError_t hipFuncSetAttribute(const void *fn, hipFuncAttribute attr, int value)
 hipError_t hipMalloc(void **p, size_t n) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_next) {
-        void *m = mmap((void *)kBase, kSpan, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED_NOREPLACE,
+        void *m = mmap((void *)kBase, kSpan, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED_NOREPLACE,
                        -1, 0);
         if (m != (void *)kBase) {
             fprintf(stderr, "hipmock: cannot map the device address space at %p\n", (void *)kBase);
@@ -159,7 +170,7 @@ hipError_t hipFree(void *p) {
         fprintf(tr(), "free %p INVALID\n", p);
         return hipErrorInvalidValue;
     }
-    madvise(p, (it->second + 4095) & ~(size_t)4095, MADV_DONTNEED);       // give the pages back, keep the addresses unique
+    madvise(p, (it->second + 4095) & ~(size_t)4095, MADV_REMOVE);         // give the pages back (shared mapping), keep the addresses unique
     g_alloc.erase(it);
     fprintf(tr(), "free %p\n", p);
     return hipSuccess;
@@ -274,6 +285,20 @@ hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_tR0600 *p, int) {
 }
 hipError_t hipGetLastError() { return hipSuccess; }
 const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "hipmock error"; }
+
+// for tests/gfx950sim: the hook that executes a launch, and the live allocations (bounds checks of simulated accesses)
+void hipmock_set_launch_hook(launch_hook_t h) { g_hook = h; }
+int hipmock_allocs(uint64_t *ptrs, uint64_t *sizes, int cap) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = 0;
+    for (auto &kv : g_alloc) {
+        if (n >= cap) break;
+        ptrs[n] = (uint64_t)(uintptr_t)kv.first;
+        sizes[n] = kv.second;
+        ++n;
+    }
+    return n;
+}
 
 // for the driver: a mark between the stages of a scenario, and a flush of the trace so far
 void hipmock_mark(const char *text) {
