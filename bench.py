@@ -454,6 +454,8 @@ def main():
 
     # ---- the other BASELINE.json configurations at their per-GPU sizes, short passes after the timed c2 region ------
     others = None
+    side_errors = []                 # failures outside the timed region: flagged in the line ("partial": true) and on stderr; the
+                                     # exit code stays 0 because the headline value is valid (its timed region ended before)
     if rank == 0 and args.config == "c2" and args.gpus == 1 and not (args.profile_only or args.no_other_configs):
         others = {}
         del wl, model
@@ -464,6 +466,8 @@ def main():
                 others[oc] = short_pass(oc, args.dtype, dev, lib)
             except Exception as e:                                   # noqa: BLE001 -- reported, not swallowed
                 others[oc] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                side_errors.append(f"{oc}: {others[oc]['error']}")
+                print(f"bench.py: side configuration {oc} FAILED: {others[oc]['error']}", file=sys.stderr, flush=True)
             torch.cuda.empty_cache()
         wl = None
 
@@ -475,6 +479,8 @@ def main():
                 base = cpu_baseline()
             except Exception as e:                                   # noqa: BLE001
                 base = {"error": f"{type(e).__name__}: {e}"[:300]}
+                side_errors.append(f"cpu_baseline: {base['error']}")
+                print(f"bench.py: cpu_baseline FAILED: {base['error']}", file=sys.stderr, flush=True)
         line = {
             "metric": metric_name,
             "value": round(imgs / elapsed, 3), "unit": "images/sec", "n_gpus": args.gpus, "steps": args.steps,
@@ -490,6 +496,7 @@ def main():
             **({"valid": False, "ablation": env_seen["BNDM_ABLATE"]} if "BNDM_ABLATE" in env_seen else {}),
             # timed on rank 0 of the single-GPU run only (the host cores are shared by the ranks otherwise)
             "cpu_baseline": base,
+            **({"partial": True, "side_errors": side_errors} if side_errors else {}),
         }
         print(json.dumps(line), flush=True)
     barrier()

@@ -492,6 +492,9 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float *__restrict__ 
     __syncthreads();                                                   // patch is dead: the tile is staged over it
     const int rowB = C0 * 2;                       // bytes per staged pixel row
     const int pl = wv * 32 + (l & 31);             // pixel inside the block
+    // the 16-byte chunks of a staged row are XOR-swizzled with the pixel index; the key must stay inside the row's C0 / 8
+    // chunks (8 at C0 = 64: with a 4-bit key pixel 15's chunks landed in pixel 16's row -- found by tests/gfx950sim)
+    const int swz = ((C0 >> 3) - 1) & 15;
     for (int n0 = 0; n0 < C0; n0 += 32) {
         f32x16 acc;
 #pragma unroll
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float *__restrict__ 
             v4 ov;
 #pragma unroll
             for (int e = 0; e < 4; ++e) ov[e] = (T)(acc[4 * g + e] + bv[e]);
-            *reinterpret_cast<v4 *>(smem + pl * rowB + ((((co >> 3) ^ (pl & 15)) << 4) | ((co & 7) * 2))) = ov;
+            *reinterpret_cast<v4 *>(smem + pl * rowB + ((((co >> 3) ^ (pl & swz)) << 4) | ((co & 7) * 2))) = ov;
         }
     }
     __syncthreads();
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float *__restrict__ 
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
     for (int p = prw; p < 128; p += RP) {
-        const v8 v = *reinterpret_cast<const v8 *>(smem + p * rowB + ((c16 ^ (p & 15)) << 4));
+        const v8 v = *reinterpret_cast<const v8 *>(smem + p * rowB + ((c16 ^ (p & swz)) << 4));
         store_wt(reinterpret_cast<v8 *>(out + (size_t)(m0 + p) * C0 + c16 * 8), v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {

@@ -67,6 +67,7 @@ class Memory:
         self.faults = []
         self.extra = []                  # (addr, numpy uint8 array) host-side segments (kernarg)
         self.undo = None                 # list of (byte indices, old bytes) while a launch is run differentially
+        self.counters = {}               # bytes moved by vector memory instructions ("load", "store"), per launch (GFX950SIM_STATS)
 
     def set_allocs(self, pairs):
         pairs = sorted(pairs)
@@ -106,6 +107,7 @@ class Memory:
         a = off[active]
         if (a & 3).any():
             raise SimError("misaligned dword access")
+        self.counters["load"] = self.counters.get("load", 0) + 4 * ndw * a.size
         idx = a[None, :] + (4 * np.arange(ndw, dtype=np.int64))[:, None]            # [ndw, n]
         b = self.u8[(idx[:, :, None] + np.arange(4, dtype=np.int64)).reshape(-1)].reshape(ndw, -1, 4)
         out[:, active] = b.view(U32).reshape(ndw, -1) if b.flags.c_contiguous else np.ascontiguousarray(b).view(U32).reshape(ndw, -1)
@@ -118,6 +120,7 @@ class Memory:
             return
         a = off[active]
         ndw = data.shape[0]
+        self.counters["store"] = self.counters.get("store", 0) + 4 * ndw * a.size
         idx = a[None, :] + (4 * np.arange(ndw, dtype=np.int64))[:, None]
         b = np.ascontiguousarray(data[:, active]).view(U8).reshape(ndw, -1, 4)
         flat = (idx[:, :, None] + np.arange(4, dtype=np.int64)).reshape(-1)

@@ -2104,10 +2104,21 @@ def _buffer_access(ins, first):
             raise SimError("buffer descriptor with a stride")
         off = (vo(w).astype(np.int64) if vo else np.zeros(64, np.int64)) + ioff
         s = so(w)
-        # raw buffer: a dword is out of range when offset + soffset + 4 > num_records
-        inr = (off + s + nbytes <= nrec) & (off >= 0)
+        # raw buffer: range-checked PER DWORD (a dwordx4 access straddling num_records returns its in-range dwords and zeros
+        # for the rest); dword j is in range when offset + soffset + 4 * j + 4 <= num_records
+        inr = [((off + s + 4 * j + 4) <= nrec) & (off >= 0) for j in range(nbytes // 4)]
         return base + s + off, inr
     return f
+
+
+def _buffer_gather(w, ins, a, inr, act, ndw):
+    data = np.zeros((ndw, 64), U32)
+    for j in range(ndw):
+        ok = act & inr[j]
+        if ok.any():
+            w.mem.check(a + 4 * j, 4, ins.text, ok)
+            data[j] = w.mem.gather(a + 4 * j, 1, ok)[0]
+    return data
 
 
 @op("buffer_load_dword", "buffer_load_dwordx2", "buffer_load_dwordx3", "buffer_load_dwordx4")
@@ -2120,9 +2131,7 @@ def _(ins):
         def run(w):
             a, inr = acc(w, 4 * ndw)
             act = w.execb.copy()
-            ok = act & inr
-            w.mem.check(a, 4 * ndw, ins.text, ok)
-            data = w.mem.gather(a, ndw, ok)                       # out-of-range lanes deliver zeros
+            data = _buffer_gather(w, ins, a, inr, act, ndw)       # out-of-range dwords deliver zeros
             _lds_dma_issue(w, ins, data, act, w.s[M0] & 0x3FFFF, 4 * ndw)
         return run
     d = dreg(ins.ops[0])[1]
@@ -2131,9 +2140,7 @@ def _(ins):
     def run(w):
         a, inr = acc(w, 4 * ndw)
         act = w.execb.copy()
-        ok = act & inr
-        w.mem.check(a, 4 * ndw, ins.text, ok)
-        data = w.mem.gather(a, ndw, ok)
+        data = _buffer_gather(w, ins, a, inr, act, ndw)
 
         def apply():
             for j in range(ndw):
@@ -2150,9 +2157,11 @@ def _(ins):
 
     def run(w):
         a, inr = acc(w, 4 * ndw)
-        ok = w.execb & inr
-        w.mem.check(a, 4 * ndw, ins.text, ok)
-        w.mem.scatter(a, w.v[r0:r0 + ndw], ok)
+        for j in range(ndw):
+            ok = w.execb & inr[j]
+            if ok.any():
+                w.mem.check(a + 4 * j, 4, ins.text, ok)
+                w.mem.scatter(a + 4 * j, w.v[r0 + j:r0 + j + 1], ok)
         w.push_vm(Pending(_nothing, what=ins.text))
     return run
 

@@ -31,6 +31,7 @@ class Launch:
         self.hazards = []
         self.strict = sim.strict
         self.ninst = 0
+        self.stats = {} if sim.collect_stats else None     # mnemonic -> executed wave-instructions
         if kernel.scratch:
             raise SimError(f"{kernel.name}: uses {kernel.scratch} bytes of scratch (not modelled)")
         if kernel.preload & 0x7F:
@@ -131,6 +132,7 @@ class Launch:
     def _run_wave(self, w, insts):
         sim = self.sim
         limit = sim.max_inst
+        stats = self.stats
         n = 0
         try:
             while True:
@@ -138,6 +140,8 @@ class Launch:
                 fn = ins.fn
                 if fn is None:
                     fn = compile_inst(ins)
+                if stats is not None:
+                    stats[ins.mnem] = stats.get(ins.mnem, 0) + 1
                 r = fn(w)
                 n += 1
                 if r is None:
@@ -168,10 +172,12 @@ class Simulator:
     def __init__(self, lib, strict=False, check_bounds=True, max_inst=20_000_000, verbose=False):
         self.kernels = loader.load_library(lib)
         self.mem = Memory()
-        self.strict = strict
+        self.strict = strict or os.environ.get("GFX950SIM_STRICT") == "1"      # the first hazard ends the run
         self.check_bounds = check_bounds
         self.max_inst = max_inst
         self.verbose = verbose
+        self.collect_stats = os.environ.get("GFX950SIM_STATS") == "1"
+        self.stats = []                  # (kernel, grid, {mnemonic: count}, {memory counter: bytes}) per launch, single-process runs only
         self.order = int(os.environ.get("GFX950SIM_ORDER", "0"))
         self.nproc = int(os.environ.get("GFX950SIM_PROCS", "1"))
         self.log = []                    # (kernel, grid, instructions, seconds, hazards)
@@ -179,6 +185,30 @@ class Simulator:
         self._hook = None
         self.hip = None
         self.skip = set()                # kernel-name substrings not to execute
+        self._tiny = set()
+        self.subst = []                  # (substring, replacement, block.x, LDS bytes) kernel-variant substitutions
+        for r in filter(None, os.environ.get("GFX950SIM_SUBST", "").split(";")):
+            frm, rest = r.split("=>")
+            to, bx, lds_ = rest.split(":")
+            self.subst.append((frm, to, int(bx), int(lds_)))
+        # sensitivity experiments: "substr:add" loosens every counted `s_waitcnt vmcnt(N > 0)` of the matching kernels by `add`
+        # (tests/gfx950sim/mutate.py) -- a correct kernel must then FAIL here
+        loosen = os.environ.get("GFX950SIM_LOOSEN")
+        if loosen:
+            sub, add = loosen.rsplit(":", 1)
+            n = 0
+            for name, k in self.kernels.items():
+                if sub in name:
+                    for ins in k.insts:
+                        if ins.mnem == "s_waitcnt":
+                            mods = []
+                            for m in ins.mods:
+                                if m.startswith("vmcnt(") and m != "vmcnt(0)":
+                                    m = f"vmcnt({int(m[6:-1]) + int(add)})"
+                                    n += 1
+                                mods.append(m)
+                            ins.mods, ins.fn = mods, None
+            print(f"[sim] loosened {n} counted vmcnt waits in kernels matching {sub!r} by {add}", flush=True)
         self.reference = None            # differential mode: callable(name, grid, block, lds, args) running a model of the launch
         self.diffs = []                  # (kernel, launch index, report lines) of launches whose stores differ from the model's
 
@@ -212,6 +242,16 @@ class Simulator:
                 raise SimError(f"launch of unknown kernel {name}")
             if any(s in name for s in self.skip):
                 return
+            dims = list(dims[0:6])
+            for rule in self.subst:
+                # run ANOTHER variant of the kernel on the recorded arguments (variants of one template share their argument
+                # list; block size and LDS size are the variant's): how the 4-wave conv_t32 -- which the library only picks for
+                # grids of >= 448 workgroups, i.e. batch >= 28 -- is executed on a batch the simulator can afford
+                if rule[0] in name:
+                    name = name.replace(rule[0], rule[1])
+                    dims[3], lds = rule[2], rule[3]
+                    k = self.kernels[name]
+                    break
             explicit = [a for a in k.args if not str(a[".value_kind"]).startswith("hidden_")]
             raw = [C.string_at(args[i], int(a[".size"])) for i, a in enumerate(explicit)]
             self._refresh_allocs()
@@ -286,11 +326,16 @@ class Simulator:
         L = Launch(self, k, list(grid), list(block), lds_dynamic, arg_bytes)
         t0 = time.time()
         nwg = grid[0] * grid[1] * grid[2]
-        if self.nproc > 1 and nwg >= 2 * self.nproc and select is None:
-            self._run_forked(L, nwg)
+        if self.nproc > 1 and nwg >= 2 and select is None and L.kernel.name not in self._tiny:
+            self._run_forked(L, nwg, min(self.nproc, nwg))
         else:
             L.run(self.order, select)
         dt = time.time() - t0
+        if dt < 0.05 and self.nproc > 1:
+            self._tiny.add(k.name)           # (a launch this short is not worth the forks next time)
+        if L.stats is not None:
+            self.stats.append((name, tuple(grid), L.stats, dict(self.mem.counters)))
+            self.mem.counters.clear()
         self.log.append((name, tuple(grid), L.ninst, dt, len(L.hazards)))
         self.hazards.extend(f"{name[:60]}: {h}" for h in L.hazards)
         if self.verbose:
@@ -298,18 +343,18 @@ class Simulator:
                   flush=True)
         return L
 
-    def _run_forked(self, L, nwg):
+    def _run_forked(self, L, nwg, nproc):
         """workgroups dealt to forked children; device memory is a MAP_SHARED region, so their stores land in place"""
         import pickle
         pids = []
-        for p in range(self.nproc):
+        for p in range(nproc):
             r, wfd = os.pipe()
             pid = os.fork()
             if pid == 0:
                 os.close(r)
                 code = 0
                 try:
-                    L.run(self.order, range(p, nwg, self.nproc))
+                    L.run(self.order, range(p, nwg, nproc))
                     os.write(wfd, pickle.dumps((L.ninst, L.hazards, None)))
                 except BaseException as e:
                     import traceback

@@ -1,0 +1,169 @@
+"""TEST INFRASTRUCTURE: the configurations run on the instruction-level simulator, and the runner that executes one of them
+(a library's machine code through tests/hipmock/exec_forward.py with EXEC_SIM=1, or tests/gfx950sim/cases.py) and compares the
+result with oracle/ -- used by tests/test_gfx950sim.py (fast subset), tools/sim_suite.sh (everything, log under profiles/) and
+tools/sim_candidates.sh (candidate libraries).
+
+    python -m tests.gfx950sim.suite [--lib lib.so] [--procs 8] [--work dir] name [name ...] | all | fast
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _subst(t):
+    """run the 4-wave conv_t32 variants (what the library picks at >= 448 workgroups, i.e. batch >= 28 at 64x64) on the
+    recorded arguments of the 8-wave launches: same argument list, the variant's block size and LDS size"""
+    return (f"conv_t32I{t}Li16ELi0ELi8ELi128ELi1E=>conv_t32I{t}Li16ELi0ELi4ELi128ELi0E:256:81920;"
+            f"conv_t32I{t}Li8ELi0ELi8ELi128ELi1E=>conv_t32I{t}Li8ELi0ELi4ELi128ELi0E:256:63488")
+
+
+S4, S4B = _subst("DF16_"), _subst("DF16b")
+
+# name -> (kind, case, batch, env, bar on rel-L2 / max-abs, what it covers)
+CONFIGS = {
+    # ---- fast subset (default CPU suite) ------------------------------------------------------------------------------
+    "steps": ("cases", "steps", None, {}, 0.0, "iadb_step x2, ddim_step, export_u8 x2: bit-exact"),
+    "noise_small64": ("cases", "noise:small64", None, {}, 1e-4, "bluenoise_small<W16> + finish, B=2 64 px"),
+    "lat_t32x4": ("unet", "lat256", 1, {"GFX950SIM_SUBST": S4}, 2e-3,
+                  "latent celeba_res256 layout (128,256,256) at 32 px: conv_t32 4-wave TH=16 / TH=8 (substituted), conv_s incl. "
+                  "64-token attention, igemm downsampler, head"),
+    # ---- full suite (tools/sim_suite.sh; RUN_SIM_SLOW=1) ------------------------------------------------------------------
+    "c2": ("unet", "c2", 1, {"EXEC_MAX_BATCH": "64"}, 2e-3, "cat_res64 3->6, the handle bench.py builds (conv_s<TM=128>), 8-wave conv_t32"),
+    "c2_t32x4": ("unet", "c2", 1, {"EXEC_MAX_BATCH": "64", "GFX950SIM_SUBST": S4}, 2e-3, "... with the DOMINANT 4-wave conv_t32<TH=16> / <TH=8>"),
+    "c2_t32x4_rev": ("unet", "c2", 1, {"EXEC_MAX_BATCH": "64", "GFX950SIM_SUBST": S4, "GFX950SIM_ORDER": "1"}, 2e-3, "... waves in reverse order"),
+    "c2_b2_random": ("unet", "c2", 2, {"GFX950SIM_ORDER": "5"}, 2e-3, "B=2 (conv_s<TM=64>), waves in random order"),
+    "c2_bf16_t32x4": ("unet", "c2bf16", 1, {"EXEC_MAX_BATCH": "64", "GFX950SIM_SUBST": S4B}, 1e-2, "bf16 storage / MFMA inputs"),
+    "c3_ddim_loop": ("unet", "c3loop", 1, {"EXEC_MAX_BATCH": "64"}, 3e-3, "church_res64 3->3: two steps of the in-engine DDIM loop"),
+    "c2_iadb_loop": ("unet", "c2loop", 1, {"EXEC_MAX_BATCH": "64"}, 2e-3, "two steps of the in-engine IADB loop with snapshots"),
+    "c4": ("unet", "c4", 1, {"EXEC_MAX_BATCH": "32", "GFX950SIM_SUBST": S4}, 2e-3, "celeba_res128 3->6 (7 levels)"),
+    "c5": ("unet", "c5", 1, {"EXEC_MAX_BATCH": "8"}, 2e-3, "latent 4->8 at c5's per-GPU batch handle"),
+    "cond": ("unet", "cond", 1, {}, 2e-3, "conditional (super-resolution) sampler, two steps"),
+    "lat256": ("unet", "lat256", 2, {}, 2e-3, "latent celeba_res256 layout, ragged batch"),
+    "w64": ("unet", "w64", 1, {}, 2e-3, "first-level width 64 (conv_in swizzle fix)"),
+    "w256": ("unet", "w256", 1, {}, 2e-3, "first-level width 256"),
+    "bottom1x1": ("unet", "bottom1x1", 2, {}, 2e-3, "1x1 bottom level: deferred split-K in front of a conv_s upsampler"),
+    "no_tail": ("unet", "c2", 1, {"BNDM_NO_TAIL": "1"}, 2e-3, "fallback: <= 8x8 levels on conv_igemm + gn_small"),
+    "no_fused": ("unet", "c2", 1, {"BNDM_NO_FUSED": "1"}, 2e-3, "fallback: no conv_t32 (igemm + materialised GroupNorm everywhere)"),
+    "f32mode": ("unet", "c2f32", 1, {}, 1e-4, "fp32-compute verification mode"),
+    "vae16": ("unet", "vae16", 1, {}, 5e-3, "AutoencoderKL decoder, full layout, 16x16 latent"),
+    "noise_small32col": ("cases", "noise:small32col", None, {}, 1e-4, "bluenoise_small<W32>, 32-px crop, GBN"),
+    "noise_gemm128": ("cases", "noise:gemm128", None, {}, 1e-4, "bluenoise_gemm, 128 px tile permutation + scrambled wn, a shard"),
+    "noise_dense64": ("cases", "noise:dense64", None, {}, 1e-4, "l_dense = 1"),
+}
+FAST = ("steps", "noise_small64", "lat_t32x4")
+
+
+def expected(case, sd, cfg, out_dir):
+    """what oracle/ computes for an exec_forward.py case -> (got, want) tensors"""
+    import numpy as np
+    import torch
+    from oracle import unet_oracle as UO
+    from tests.hipmock.exec_forward import CASES, DA, DDIM, DG, T_IN
+    cin, cout, res, layout, B, mode = CASES[case]
+    load = lambda what: torch.from_numpy(np.load(os.path.join(out_dir, f"exec_{case}_{what}.npy")))
+    x = load("x")
+    if mode == "vae":
+        from oracle import vae_oracle as VO
+        want = VO.decode(sd, cfg, x)
+    elif mode == "forward":
+        want = UO.forward(sd, cfg, x, load("t"))
+    elif mode in ("iadb", "cond"):
+        extra = load("extra") if mode == "cond" else None
+        snaps = []
+        for s in range(2):                                   # utils.py:196-226 / iadb_bn.py:384-438 with explicit tables
+            d = UO.forward(sd, cfg, x if extra is None else torch.cat([x, extra], 1), T_IN[s])
+            x = x + DA[s] * d[:, :x.shape[1]]
+            if cout == 2 * x.shape[1]:
+                x = x + DG[s] * d[:, x.shape[1]:]
+            snaps.append(x)
+        want = torch.stack(snaps)
+    else:
+        for s in range(2):                                   # ddim_diffusers.py:674-681
+            t, sat, s1at, sap, s1ap = DDIM[5 * s:5 * s + 5]
+            eps = UO.forward(sd, cfg, x, t)
+            x0 = ((x - s1at * eps) / sat).clamp(-1.0, 1.0)
+            x = sap * x0 + s1ap * eps
+        want = x
+    return load("out"), want
+
+
+def run_config(name, lib=None, work=None, procs=8):
+    """-> dict(name, ok, value, bar, hazards, launches, wave_instructions, seconds, detail)"""
+    import subprocess
+    from tests.hipmock import harness as H
+    kind, case, batch, env, bar, what = CONFIGS[name]
+    lib = os.path.abspath(lib or H.PRODUCT_LIB)
+    work = work or os.path.join("/tmp", "gfx950sim_work")
+    os.makedirs(work, exist_ok=True)
+    H.build_mock(work)
+    t0 = time.time()
+    env = dict(env, GFX950SIM_PROCS=str(procs), OMP_NUM_THREADS="4", MKL_NUM_THREADS="4")
+    if kind == "cases":
+        e = dict(os.environ, **env, LD_LIBRARY_PATH=work + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""),
+                 HIPMOCK_TRACE=os.path.join(work, f"trace_cases_{name}.txt"), HIPMOCK_KERNARGS=H.kernargs_file(lib, work))
+        if os.path.exists(e["HIPMOCK_TRACE"]):
+            os.remove(e["HIPMOCK_TRACE"])
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gfx950sim", "cases.py"), lib, case], env=e, capture_output=True, text=True,
+                           timeout=3000)
+        line = next((ln for ln in r.stdout.splitlines() if ln.startswith("{")), None)
+        if line is None:
+            return dict(name=name, ok=False, detail=(r.stdout + r.stderr)[-3000:], seconds=time.time() - t0, what=what)
+        j = json.loads(line)
+        vals = [v for k, v in j.items() if isinstance(v, float) and k != "seconds"]
+        return dict(name=name, ok=bool(j["ok"]) and r.returncode == 0, value=max(vals) if vals else 0.0, bar=bar, hazards=len(j["hazards"]),
+                    launches=j["launches"], wave_instructions=j["wave_instructions"], seconds=round(time.time() - t0, 1), detail=j, what=what)
+    from tests import test_launch_trace as T
+    import torch
+    torch.set_num_threads(4)
+    cfg, key, make = T._case_network(case)
+    sd, wfile = T.oracle_weights(work, key, make)
+    out_dir = os.path.join(work, name)
+    env["EXEC_SIM"] = "1"
+    if batch is not None:
+        env["EXEC_BATCH"] = str(batch)
+    try:
+        out = H.run_script("exec_forward.py", lib, out_dir, out_dir, case, wfile, env=env, mockdir=work)
+    except AssertionError as e:
+        return dict(name=name, ok=False, detail=str(e)[-3000:], seconds=round(time.time() - t0, 1), what=what)
+    got, want = expected(case, sd, cfg, out_dir)
+    rel = float((got - want).double().norm() / want.double().norm())
+    import re
+    m = re.search(r"OK simulated (\d+) launches; output rms [0-9.]+; hazards (\d+)", out)
+    ninst = sum(int(x) for x in re.findall(r"launches\s+(\d+) wave-instructions", out))
+    hz = int(m.group(2)) if m else -1
+    return dict(name=name, ok=bool(m) and hz == 0 and rel <= bar, value=rel, bar=bar, hazards=hz, launches=int(m.group(1)) if m else 0,
+                wave_instructions=ninst, seconds=round(time.time() - t0, 1), detail=out[-1500:], what=what)
+
+
+def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib")
+    ap.add_argument("--procs", type=int, default=8)
+    ap.add_argument("--work")
+    ap.add_argument("names", nargs="+")
+    a = ap.parse_args()
+    names = list(CONFIGS) if a.names == ["all"] else list(FAST) if a.names == ["fast"] else a.names
+    import hashlib
+    from tests.hipmock import harness as H
+    lib = os.path.abspath(a.lib or H.PRODUCT_LIB)
+    print(f"library: {hashlib.sha256(open(lib, 'rb').read()).hexdigest()}  {lib}", flush=True)
+    bad = 0
+    for n in names:
+        r = run_config(n, lib, a.work, a.procs)
+        v = r.get("value")
+        print(f"{'PASS' if r['ok'] else 'FAIL'}  {n:18s} value {v if v is None else format(v, '.3e')} (bar {r.get('bar')})  hazards {r.get('hazards')}  "
+              f"{r.get('launches', 0)} launches  {r.get('wave_instructions', 0)} wave-instructions  {r['seconds']} s   -- {r['what']}", flush=True)
+        if not r["ok"]:
+            bad += 1
+            print("      " + str(r.get("detail"))[-2500:].replace("\n", "\n      "), flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -748,6 +748,9 @@ def main():
             print(f"   {k:24s} {n_:4d} launches {ni:11d} wave-instructions {dt:8.1f} s")
         for hz in sim.hazards[:20]:
             print("HAZARD", hz)
+        if sim.stats:                                          # GFX950SIM_STATS=1 (single process): executed instructions by mnemonic
+            json.dump([dict(kernel=n_, grid=g_, insts=st_, bytes=by_) for n_, g_, st_, by_ in sim.stats],
+                      open(os.path.join(outdir, f"sim_stats_{case}.json"), "w"))
         return
     dev(x.value, np.float32, xin.size)[:] = xin.ravel()    # (nothing ran: the state is still x0; written again for clarity)
     lines = open(os.environ["HIPMOCK_TRACE"]).read().splitlines()

@@ -1,16 +1,29 @@
 """Host side of libbndm_hip.so without a GPU: the library runs against a recording stand-in for the HIP runtime
-(tests/hipmock: kernels are recorded, never executed) and its trace -- launch list, grids, LDS sizes, kernel-argument bytes,
-table uploads, buffer layout -- is compared with the digest of the build the full GPU suite passed on
-(tests/golden/launch_traces.json).  No compute happens here; what this pins is that a later build asks the GPU for exactly
-the same work, in the same order, on the same buffers, as the one that was validated on hardware."""
+(tests/hipmock: kernels are recorded, not executed here) and its trace -- launch list, grids, LDS sizes, kernel-argument bytes,
+table uploads, buffer layout -- is compared with the digest of the PINNED build (tests/golden/launch_traces.json).  What backs
+the pinned build is written in the fixture ("validated_by": a committed GPU-suite log naming its sha256, or, while no GPU is
+reachable, the simulator suite's log -- tests/gfx950sim executes the machine code on the CPU); the tests below check that the
+named log exists and names that library.  What this pins: a later build asks the GPU for exactly the same work, in the same
+order, on the same buffers, with the same machine code, as the pinned one."""
 import json
 import os
+
+import shutil
 
 import pytest
 
 from tests.hipmock import harness as H
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "launch_traces.json")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# everything here runs the built library under a stand-in compiled on the spot and reads its code objects with the ROCm LLVM
+# tools: skip (do not error) on a box without them
+_NEED = ["/opt/rocm/lib/llvm/bin/llvm-readelf", "/opt/rocm/include/hip/hip_runtime_api.h"]
+pytestmark = [
+    pytest.mark.skipif(not os.path.exists(H.PRODUCT_LIB), reason="bndm_amd/libbndm_hip.so has not been built (__graft_entry__.build())"),
+    pytest.mark.skipif(not all(os.path.exists(p) for p in _NEED) or not shutil.which("g++") or not shutil.which("objcopy"),
+                       reason="needs the ROCm LLVM tools, the HIP headers, g++ and objcopy"),
+]
 
 
 @pytest.fixture(scope="module")
@@ -109,7 +122,7 @@ def _first_difference(got, want):
         if g == w:
             continue
         if g["stage"] != w["stage"]:
-            return f"stage order: got '{g['stage']}', validated build had '{w['stage']}'"
+            return f"stage order: got '{g['stage']}', pinned build had '{w['stage']}'"
         if g["calls"] != w["calls"]:
             return f"stage '{g['stage']}': calls {g['calls']} vs validated {w['calls']}"
         for i, (a, b) in enumerate(zip(g["launches"], w["launches"])):
@@ -120,14 +133,14 @@ def _first_difference(got, want):
 
 
 @pytest.mark.parametrize("scenario", H.SCENARIOS)
-def test_host_side_matches_the_gpu_validated_build(scenario, workdir, gold):
+def test_host_side_matches_the_pinned_build(scenario, workdir, gold):
     lines = scenario_trace(scenario, workdir)
     assert H.check_pointers(lines) > 0
     got = H.digest(lines)
     want = gold["scenarios"][scenario]
-    assert got == want, ("the library's host side differs from the build validated on the GPU (" + gold["library_sha256"][:12] +
-                         "): " + _first_difference(got, want) + " -- if intended, run the GPU suite on this build first, "
-                         "then tests/golden/make_launch_traces.py")
+    assert got == want, ("the library's host side differs from the pinned build (" + gold["library_sha256"][:12] + ", backed by " +
+                         str(gold.get("validated_by")) + "): " + _first_difference(got, want) + " -- if intended, validate this build "
+                         "(GPU suite, or tools/sim_suite.sh while no GPU is reachable), then tests/golden/make_launch_traces.py")
 
 
 def test_launch_list_of_the_headline_workload(workdir):
@@ -152,14 +165,48 @@ def test_launch_list_of_the_headline_workload(workdir):
     assert sum(1 for x in loop if x.startswith("memcpy_async") and "src=0x" in x) == 2
 
 
-def test_device_code_is_the_gpu_validated_build(gold):
-    """the gfx950 code objects inside the library are byte for byte those of the build the GPU suite passed on: together
-    with the identical host trace above, a rebuilt library behaves exactly like the validated one"""
+def _same_toolchain(gold):
+    from tests.golden.make_launch_traces import hipcc_version
+    return gold.get("hipcc_version") in (None, hipcc_version())
+
+
+def test_device_code_is_the_pinned_build(gold):
+    """the gfx950 code objects inside the library are byte for byte those of the pinned build: together with the identical
+    host trace above, a rebuilt library behaves exactly like the pinned one.  (Compiler output: skipped under another hipcc.)"""
     import hashlib
     from tests.hipmock.kernargs import code_objects
+    if not _same_toolchain(gold):
+        pytest.skip(f"the fixture was cut with '{gold.get('hipcc_version')}': another compiler's output is not comparable byte for byte")
     got = [hashlib.sha256(co).hexdigest() for co in code_objects(H.PRODUCT_LIB)]
-    assert got == gold["device_code_sha256"], "device code differs from the GPU-validated build: run the GPU suite, then " \
-                                              "tests/golden/make_launch_traces.py"
+    assert got == gold["device_code_sha256"], "device code differs from the pinned build: validate the new build (GPU suite / " \
+                                              "tools/sim_suite.sh), then tests/golden/make_launch_traces.py"
+
+
+def test_the_pinned_build_is_backed_by_a_committed_log(gold):
+    """the fixture names what validated the pinned library -- a GPU-suite log or the simulator suite's log -- and that log,
+    committed under profiles/, names the library's sha256 (the round-5 fixture pinned the build to itself)"""
+    vb = gold.get("validated_by")
+    assert vb, "tests/golden/launch_traces.json carries no 'validated_by'"
+    path = vb.split(":", 1)[1] if vb.startswith("sim:") else vb
+    full = os.path.join(ROOT, path)
+    assert os.path.exists(full), f"{path} is not in the tree"
+    assert gold["library_sha256"] in open(full).read(), f"{path} does not name the pinned library {gold['library_sha256'][:16]}"
+
+
+def test_kernels_unchanged_since_the_driver_green_build(gold):
+    """per KERNEL: which machine code is byte-identical to the last build the DRIVER ran green (round 3, commit f458ce0, library
+    823a75b0...) is recorded when the fixture is cut; a later build may only shrink that list knowingly"""
+    if not _same_toolchain(gold):
+        pytest.skip("another hipcc: machine code is not comparable byte for byte")
+    from tests.golden.make_launch_traces import kernel_hashes
+    now = kernel_hashes(H.PRODUCT_LIB)
+    assert now == gold["kernel_code_sha256"], sorted(k for k in now if gold["kernel_code_sha256"].get(k) != now[k])[:5]
+    same, changed = gold["kernels_equal_to_r03_green"], gold["kernels_changed_since_r03_green"]
+    assert gold["r03_green_library_sha256"].startswith("823a75b0")
+    assert len(same) + len(changed) == len(now)
+    # what changed since the driver-green build: the conv_t32 family (round 4: lean normalisation, pinned phases) and conv_in
+    # (round 6: first-level width 64 swizzle fix) -- nothing else
+    assert all("conv_t32" in k or "conv_in_kernel" in k for k in changed), [k for k in changed if "conv_t32" not in k and "conv_in" not in k]
 
 
 def test_conv_t32_launches_compute_their_layers(workdir):
