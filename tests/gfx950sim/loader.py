@@ -125,6 +125,70 @@ def _metadata(path):
     return yaml.safe_load(doc)["amdhsa.kernels"]
 
 
+def parse_code_object(co):
+    """one gfx950 ELF code object (bytes) -> {kernel symbol: KernelInfo}"""
+    kernels = {}
+    with tempfile.NamedTemporaryFile(suffix=".elf") as f:
+        f.write(co)
+        f.flush()
+        dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--mcpu=gfx950", f.name], check=True, capture_output=True,
+                             text=True).stdout
+        meta = _metadata(f.name)
+    kds = _elf_kd(co)
+    cur = None
+    for line in dis.splitlines():
+        m = re.match(r"^([0-9a-f]{16}) <(.+)>:$", line)
+        if m:
+            cur = KernelInfo(m.group(2))
+            cur.entry = int(m.group(1), 16)
+            kernels[cur.name] = cur
+            continue
+        if cur is None:
+            continue
+        ins = parse_line(line)
+        if ins is not None:
+            cur.index[ins.addr] = len(cur.insts)
+            cur.insts.append(ins)
+    for k in meta:
+        ki = kernels.get(k[".name"])
+        if ki is None:
+            continue
+        ki.args = k.get(".args", [])
+        ki.kernarg_size = int(k.get(".kernarg_segment_size", 0))
+        ki.lds_static = int(k.get(".group_segment_fixed_size", 0))
+        ki.scratch = int(k.get(".private_segment_fixed_size", 0))
+        ki.vgpr_count, ki.agpr_count, ki.sgpr_count = int(k.get(".vgpr_count", 0)), int(k.get(".agpr_count", 0)), int(k.get(".sgpr_count", 0))
+        kd, _ = kds[k[".name"]]
+        ki.rsrc3, ki.rsrc1, ki.rsrc2 = struct.unpack_from("<III", kd, 44)
+        ki.code_props, ki.preload = struct.unpack_from("<HH", kd, 56)
+        (entry_off,) = struct.unpack_from("<q", kd, 16)
+        assert kds[k[".name"]][1] + entry_off == ki.entry, (k[".name"], hex(kds[k[".name"]][1] + entry_off), hex(ki.entry))
+    return kernels
+
+
+def load_code_object_file(path):
+    """a stand-alone code object (hipcc --genco / --cuda-device-only -c, unbundled) -> {kernel symbol: KernelInfo}"""
+    blob = open(path, "rb").read()
+    if blob[:4] != b"\x7fELF":
+        i = blob.find(b"\x7fELF")
+        assert i >= 0, f"{path}: no ELF inside"
+        # a clang offload bundle: take the gfx950 entry
+        from tests.hipmock.kernargs import MAGIC
+        if blob.startswith(MAGIC):
+            (n,) = struct.unpack_from("<Q", blob, len(MAGIC))
+            q = len(MAGIC) + 8
+            for _ in range(n):
+                off, size, idlen = struct.unpack_from("<QQQ", blob, q)
+                ident = blob[q + 24:q + 24 + idlen].decode()
+                q += 24 + idlen
+                if "gfx950" in ident and size:
+                    blob = blob[off:off + size]
+                    break
+        else:
+            blob = blob[i:]
+    return parse_code_object(blob)
+
+
 def load_library(lib):
     """-> {kernel symbol: KernelInfo}; cached by the library's sha256"""
     blob = open(lib, "rb").read()
@@ -136,41 +200,7 @@ def load_library(lib):
             return pickle.load(f)
     kernels = {}
     for co in code_objects(lib):
-        with tempfile.NamedTemporaryFile(suffix=".elf") as f:
-            f.write(co)
-            f.flush()
-            dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--mcpu=gfx950", f.name], check=True, capture_output=True,
-                                 text=True).stdout
-            meta = _metadata(f.name)
-        kds = _elf_kd(co)
-        cur = None
-        for line in dis.splitlines():
-            m = re.match(r"^([0-9a-f]{16}) <(.+)>:$", line)
-            if m:
-                cur = KernelInfo(m.group(2))
-                cur.entry = int(m.group(1), 16)
-                kernels[cur.name] = cur
-                continue
-            if cur is None:
-                continue
-            ins = parse_line(line)
-            if ins is not None:
-                cur.index[ins.addr] = len(cur.insts)
-                cur.insts.append(ins)
-        for k in meta:
-            ki = kernels.get(k[".name"])
-            if ki is None:
-                continue
-            ki.args = k.get(".args", [])
-            ki.kernarg_size = int(k.get(".kernarg_segment_size", 0))
-            ki.lds_static = int(k.get(".group_segment_fixed_size", 0))
-            ki.scratch = int(k.get(".private_segment_fixed_size", 0))
-            ki.vgpr_count, ki.agpr_count, ki.sgpr_count = int(k.get(".vgpr_count", 0)), int(k.get(".agpr_count", 0)), int(k.get(".sgpr_count", 0))
-            kd, _ = kds[k[".name"]]
-            ki.rsrc3, ki.rsrc1, ki.rsrc2 = struct.unpack_from("<III", kd, 44)
-            ki.code_props, ki.preload = struct.unpack_from("<HH", kd, 56)
-            (entry_off,) = struct.unpack_from("<q", kd, 16)
-            assert kds[k[".name"]][1] + entry_off == ki.entry, (k[".name"], hex(kds[k[".name"]][1] + entry_off), hex(ki.entry))
+        kernels.update(parse_code_object(co))
     with open(cpath, "wb") as f:
         pickle.dump(kernels, f)
     return kernels

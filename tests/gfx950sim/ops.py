@@ -665,6 +665,10 @@ def _ffbh(a):
     return out
 
 
+def _popc(a):
+    return np.unpackbits(np.ascontiguousarray(a).view(U8).reshape(64, 4), axis=1).sum(1).astype(U32)
+
+
 def _brev(a):
     b = np.unpackbits(a.view(U8).reshape(64, 4), axis=1, bitorder="little")     # [64, 32] LSB first
     return np.packbits(b[:, ::-1], axis=1, bitorder="little").view(U32).reshape(64)
@@ -751,6 +755,7 @@ VALU = {
     "v_not_b32": (1, "u", lambda a: ~a),
     "v_bfrev_b32": (1, "u", _brev),
     "v_ffbh_u32": (1, "u", _ffbh),
+    "v_bcnt_u32_b32": (2, "u", lambda a, b: _popc(a) + b),
     "v_add_u32": (2, "u", lambda a, b: a + b),
     "v_sub_u32": (2, "u", lambda a, b: a - b),
     "v_subrev_u32": (2, "u", lambda a, b: b - a),
@@ -1722,7 +1727,7 @@ def _lds_read_builder(ndw, naddr=1, stride=0):
             act = w.execb.copy()
             data = np.zeros((nreg, 64), U32)
             for k, off in enumerate(offs):
-                addr = base + off
+                addr = (base + off) & M32          # the LDS address is a 32-bit sum
                 _lds_check(w, addr, 4 * ndw, act, ins.text)
                 a = addr[act] >> 2
                 for j in range(ndw):
@@ -1754,7 +1759,7 @@ def _lds_read_small(nbytes, signed, d16=None):
 
         def run(w):
             w.flush_own_lds_writes()
-            addr = va(w).astype(np.int64) + off
+            addr = (va(w).astype(np.int64) + off) & M32
             act = w.execb.copy()
             a = addr[act]
             if (a + nbytes > w.wg.lds_size).any():
@@ -1804,7 +1809,7 @@ def _lds_write_builder(ndw, naddr=1, stride=0):
             act = w.execb.copy()
             items = []
             for k, off in enumerate(offs):
-                addr = base + off
+                addr = (base + off) & M32          # the LDS address is a 32-bit sum
                 _lds_check(w, addr, 4 * ndw, act, ins.text, write=True)
                 f, r0, n = datas[k]
                 if w.npend and w.vpend[r0:r0 + ndw].any():
@@ -1839,7 +1844,7 @@ def _lds_write_small(nbytes, hi=False):
         off = mod_val(ins, "offset", 0)
 
         def run(w):
-            addr = va(w).astype(np.int64) + off
+            addr = (va(w).astype(np.int64) + off) & M32
             act = w.execb.copy()
             a = addr[act]
             if (a + nbytes > w.wg.lds_size).any():
@@ -1894,7 +1899,7 @@ def _(ins):
 
     def run(w):
         w.flush_own_lds_writes()
-        addr = (va(w).astype(np.int64) + off)
+        addr = (va(w).astype(np.int64) + off) & M32
         lds32 = w.wg.lds32
         for l in np.nonzero(w.execb)[0]:
             a = int(addr[l]) >> 2

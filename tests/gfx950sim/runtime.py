@@ -354,11 +354,12 @@ class Simulator:
                 os.close(r)
                 code = 0
                 try:
+                    self.mem.counters.clear()
                     L.run(self.order, range(p, nwg, nproc))
-                    os.write(wfd, pickle.dumps((L.ninst, L.hazards, None)))
+                    os.write(wfd, pickle.dumps((L.ninst, L.hazards, None, L.stats, dict(self.mem.counters))))
                 except BaseException as e:
                     import traceback
-                    os.write(wfd, pickle.dumps((L.ninst, L.hazards, traceback.format_exc()[-3000:])))
+                    os.write(wfd, pickle.dumps((L.ninst, L.hazards, traceback.format_exc()[-3000:], None, {})))
                     code = 1
                 os._exit(code)
             os.close(wfd)
@@ -374,10 +375,15 @@ class Simulator:
             os.close(r)
             os.waitpid(pid, 0)
             if buf:
-                n, hz, e = pickle.loads(buf)
+                n, hz, e, st, ctr = pickle.loads(buf)
                 L.ninst += n
                 L.hazards.extend(hz)
                 err = err or e
+                if st and L.stats is not None:
+                    for k_, v_ in st.items():
+                        L.stats[k_] = L.stats.get(k_, 0) + v_
+                for k_, v_ in ctr.items():
+                    self.mem.counters[k_] = self.mem.counters.get(k_, 0) + v_
             else:
                 err = err or "worker died"
         if err:

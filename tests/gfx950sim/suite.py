@@ -46,6 +46,7 @@ CONFIGS = {
     "lat256": ("unet", "lat256", 2, {}, 2e-3, "latent celeba_res256 layout, ragged batch"),
     "w64": ("unet", "w64", 1, {}, 2e-3, "first-level width 64 (conv_in swizzle fix)"),
     "w256": ("unet", "w256", 1, {}, 2e-3, "first-level width 256"),
+    "w64x4": ("unet", "w64x4", 2, {}, 2e-3, "(64, 64, 128, 256) with 8x8 attention, B=2: test_gpu_first_level_widths.py's second layout"),
     "bottom1x1": ("unet", "bottom1x1", 2, {}, 2e-3, "1x1 bottom level: deferred split-K in front of a conv_s upsampler"),
     "no_tail": ("unet", "c2", 1, {"BNDM_NO_TAIL": "1"}, 2e-3, "fallback: <= 8x8 levels on conv_igemm + gn_small"),
     "no_fused": ("unet", "c2", 1, {"BNDM_NO_FUSED": "1"}, 2e-3, "fallback: no conv_t32 (igemm + materialised GroupNorm everywhere)"),

@@ -645,6 +645,7 @@ CASES = {
     "lat256": (4, 8, 32, ((128, 256, 256), 2, 0), 5, "forward"),       # latent celeba_res256: 64-token attention, ragged batch
     "w64": (3, 6, 64, ((64, 128, 128), 2, 0), 3, "forward"),           # groups of two channels; 64 + 128 = 192-channel concats
     "w256": (3, 6, 32, ((256, 256, 512), 2, 0), 1, "forward"),
+    "w64x4": (3, 6, 64, ((64, 64, 128, 256), 3, 0), 2, "forward"),      # tests/test_gpu_first_level_widths.py's second layout: 8x8 attention
     "bottom1x1": (3, 6, 32, drive.RES64, 3, "forward"),    # the res64 layout on 32x32 inputs: last level 1x1, deferred split-K in
                                                            # front of a conv_s upsampler (round-3 advisor finding), ragged batch 3
     "c2bf16": (3, 6, 64, drive.RES64, 1, "forward"),       # bf16 storage / MFMA inputs (case name ends in bf16)

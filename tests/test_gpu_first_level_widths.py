@@ -1,10 +1,12 @@
-"""NOT collected by `pytest tests/` on purpose: written while GPU access was closed (round 4), never run.  Move into tests/ once
-it has passed on a GPU:   python -m pytest tools/experiments/extra_tests -m gpu -q -s
+"""Networks whose first level is 64 or 256 channels wide (block_out_channels[0] in {64, 128, 256}) against the
+oracle: with 64 channels GroupNorm(32) has groups of TWO channels and concatenations such as 64 + 128 = 192 give groups of six;
+no other test runs such a layout through the fused engine.
 
-Networks whose first level is 64 or 256 channels wide (block_out_channels[0] in {64, 128, 256}) against the
-oracle: with 64 channels GroupNorm(32) has groups of TWO channels -- the smallest group the per-channel-pair statistics of the
-round-4 patch (tools/experiments/round4_pairstats_sumsfirst_th32.patch) can express -- and concatenations such as 64 + 128 = 192
-give groups of six; no test in tests/ runs such a layout through the fused engine."""
+History: written in round 4 while GPU access was closed, parked outside tests/ until it had run.  It still has not run on a GPU
+(access closed through round 6) -- but its layouts have run on the instruction-level simulator (tests/gfx950sim, configurations
+w64 / w64x4 / w256 of tests/gfx950sim/suite.py), which found that the 64-wide cases would have FAILED here: conv_in's staged
+tile used a 4-bit swizzle key on rows of 8 chunks (fixed in round 6).  Moved into tests/ with that fix; the simulator figures
+are in profiles/r06_sim_suite.log (w64 1.1e-3, w256 1.0e-3 against this test's bar of 2e-3)."""
 import pytest
 import torch
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Step 3 of tools/next_gpu_session.sh: drain the candidate queue, singles only.  Run from the repo root on the GPU box.
-R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out; exec > >(tee gpurun_out/r05_candidates.log) 2>&1
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out; exec > >(tee gpurun_out/r06_candidates.log) 2>&1
 echo "shipped: $(sha256sum bndm_amd/libbndm_hip.so)"
 echo "== hashes (c2, c4): the three bit-identical-by-construction candidates must print the shipped library's line"
 for c in c2 c4; do for l in bndm_amd/libbndm_hip.so tools/lib_v9.so tools/lib_v12.so tools/lib_v13.so; do
@@ -20,5 +20,16 @@ for e in "" "BNDM_NO_TAIL=1" "BNDM_TH16_MIN=1"; do
 import json,sys
 d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}; print(d['value'], 'images/s;', r.get('ms_per_forward_total'), 'ms per forward,', r.get('launches_total'), 'launches')"
 done
-echo "== first-level widths 64 / 256 (parked test; on the shipped library)"
-timeout 600 python -m pytest tools/experiments/extra_tests/test_gpu_first_level_widths.py -m gpu -q 2>&1 | tail -4
+echo "== v16 (64-channel conv_t32 n-tiles for small-batch handles): c5 with BNDM_NCO64_MAX = 128 / 256 / 512 against the shipped library"
+mkdir -p /tmp/v16 && cp -r bndm_amd tests oracle include bluenoise utils.py iadb_bn.py ddim_diffusers.py latent_iadb_bn_diffusers.py input_args.py pytest.ini __graft_entry__.py bench.py /tmp/v16/ 2>/dev/null && cp tools/lib_v16.so /tmp/v16/bndm_amd/libbndm_hip.so
+for e in "" "BNDM_NCO64_MAX=128" "BNDM_NCO64_MAX=256" "BNDM_NCO64_MAX=512"; do
+  echo -n "-- c5 v16 ${e:-off}:  "
+  (cd /tmp/v16 && env $e timeout 600 python bench.py --config c5 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}; print(d['value'], 'images/s;', r.get('ms_per_forward_total'), 'ms per forward,', r.get('launches_total'), 'launches')")
+done
+(cd /tmp/v16 && BNDM_NCO64_MAX=256 timeout 900 python -m pytest tests/test_gpu_benched.py tests/test_gpu_unet.py -m gpu -q -x 2>&1 | tail -3)
+echo "== v17 (dedicated head kernel + Euler epilogue, supersedes v15): the loop / head tests of tests/ on the candidate, then a timed A/B"
+mkdir -p /tmp/v17 && cp -r bndm_amd tests oracle include bluenoise utils.py iadb_bn.py ddim_diffusers.py latent_iadb_bn_diffusers.py input_args.py pytest.ini __graft_entry__.py bench.py /tmp/v17/ 2>/dev/null && cp tools/lib_v17.so /tmp/v17/bndm_amd/libbndm_hip.so
+(cd /tmp/v17 && timeout 1200 python -m pytest tests/test_gpu_steps.py tests/test_gpu_tail.py tests/test_gpu_benched.py tests/test_gpu_unet.py tests/test_gpu_cli.py -m gpu -q -x 2>&1 | tail -4)
+timeout 900 python tools/ab_libs.py --rounds 2 --full bndm_amd/libbndm_hip.so tools/lib_v17.so 2>&1 | tail -8

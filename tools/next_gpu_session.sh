@@ -2,9 +2,11 @@
 # What to run when a GPU is available, in this order, ONE gpurun call per step (each is time-boxed on its own):
 #
 #   0. on the build box:  make -C bndm_amd/csrc && bash tools/build_candidates.sh && bash tools/ubench/build.sh
-#   1. gpurun --timeout 1800 -- 'bash tools/gpu_suite.sh r05'
-#        the full `-m gpu` suite + smoke() on the SHIPPED library, sha256 in the log -> copy gpurun_out/r05_gpu_tests.log to profiles/
-#   2. gpurun --timeout 1800 -- 'bash tools/profile_round.sh r05'
+#      (no GPU needed, and a gate for step 3: bash tools/sim_suite.sh rNN; bash tools/sim_candidates.sh rNN -- a candidate whose machine
+#      code does not reproduce the oracle on the instruction-level simulator with zero hazards gets no GPU minutes)
+#   1. gpurun --timeout 1800 -- 'bash tools/gpu_suite.sh r06'
+#        the full `-m gpu` suite + smoke() on the SHIPPED library, sha256 in the log -> copy gpurun_out/r06_gpu_tests.log to profiles/
+#   2. gpurun --timeout 1800 -- 'bash tools/profile_round.sh r06'
 #        PMC traffic keyed to the library's sha, bench line with per-op HIP events, rocprofv3 kernel stats, SQ counters
 #   3. gpurun --timeout 2400 -- 'bash tools/gpu_candidates.sh'            (time-box: 60 GPU-minutes over all its runs)
 #        single-patch candidate libraries, bit-identical ones first: hash against the shipped library, one interleaved A/B
