@@ -197,6 +197,8 @@ class Wave:
         self.ninst = 0
         self.clock = 1000 + 17 * wid
         self.mem = wg.launch.mem
+        nscr = (kernel.scratch + 3) // 4
+        self.scratch = np.zeros((nscr, 64), U32) if nscr else None      # private segment: register spill slots, per lane
 
     # --- exec -----------------------------------------------------------------------------------------------------
     def set_exec(self, m):

@@ -1086,10 +1086,30 @@ def _(ins):
 @op("v_cndmask_b32")
 def _(ins):
     d = dreg(ins.ops[0])[1]
-    a, b = vsrc(ins.ops[1], "f32"), vsrc(ins.ops[2], "f32")
-    m = ssrc64(ins.ops[3]) if len(ins.ops) > 3 else (lambda w: w.s[VCC] | (w.s[VCC + 1] << 32))
-    if "sdwa" in ins.mnem or "dpp" in ins.mnem:
+    if "dpp" in ins.mnem:
         raise SimError(f"unsupported form `{ins.text}`")
+    m = ssrc64(ins.ops[3]) if len(ins.ops) > 3 else (lambda w: w.s[VCC] | (w.s[VCC + 1] << 32))
+    if "sdwa" in ins.mnem:
+        srcs = []
+        for i in (0, 1):
+            o = Opnd(ins.ops[1 + i])
+            raw = Opnd(o.text)
+            raw.neg = raw.abs = raw.sext = False
+            sel = next((x.split(":")[1] for x in ins.mods if x.startswith(f"src{i}_sel:")), "DWORD")
+            srcs.append(sdwa_src(vsrc(raw, "f32"), sel, o.sext, "u", o.neg, o.abs))
+        dsel = next((x.split(":")[1] for x in ins.mods if x.startswith("dst_sel:")), "DWORD")
+        dun = next((x.split(":")[1] for x in ins.mods if x.startswith("dst_unused:")), "UNUSED_PAD")
+        a, b = srcs
+
+        def run(w):
+            r = np.where(mask_to_bool(m(w)), b(w), a(w))
+            if dsel != "DWORD":
+                sh, mk = _SEL[dsel]
+                piece = (r & U32(mk)) << U32(sh)
+                r = (w.v[d] & U32(~(mk << sh) & M32)) | piece if dun == "UNUSED_PRESERVE" else piece
+            w.wv(d, r)
+        return run
+    a, b = vsrc(ins.ops[1], "f32"), vsrc(ins.ops[2], "f32")
     return lambda w: w.wv(d, np.where(mask_to_bool(m(w)), b(w), a(w)))
 
 
@@ -2216,6 +2236,40 @@ def _(ins):
         else:
             w.push_vm(Pending(_nothing, what=ins.text))
     return run
+
+
+# scratch (register spills only): `scratch_store_dword off, vdata, off offset:N` / `scratch_load_dword vdst, off, off offset:N` -- a per-lane
+# private slot addressed by the immediate offset alone
+def _scratch(ins, store, ndw):
+    if store:
+        assert ins.ops[0] == "off" and ins.ops[2] == "off", f"scratch addressing of `{ins.text}`"
+        r0 = dreg(ins.ops[1])[1]
+    else:
+        assert ins.ops[1] == "off" and ins.ops[2] == "off", f"scratch addressing of `{ins.text}`"
+        r0 = dreg(ins.ops[0])[1]
+    slot = mod_val(ins, "offset", 0) // 4
+
+    def run(w):
+        if w.scratch is None or slot + ndw > w.scratch.shape[0]:
+            raise SimError(f"{ins.text}: beyond the kernel's private segment")
+        act = w.execb.copy()
+        if store:
+            for j in range(ndw):
+                np.copyto(w.scratch[slot + j], w.v[r0 + j], where=act)
+            w.push_vm(Pending(_nothing, what=ins.text))
+        else:
+            data = w.scratch[slot:slot + ndw].copy()
+
+            def apply():
+                for j in range(ndw):
+                    np.copyto(w.v[r0 + j], data[j], where=act)
+            w.push_vm(Pending(apply, regs=tuple(range(r0, r0 + ndw)), what=ins.text))
+    return run
+
+
+for _n, _k in (("dword", 1), ("dwordx2", 2), ("dwordx3", 3), ("dwordx4", 4)):
+    BUILDERS[f"scratch_store_{_n}"] = (lambda k: lambda ins: _scratch(ins, True, k))(_k)
+    BUILDERS[f"scratch_load_{_n}"] = (lambda k: lambda ins: _scratch(ins, False, k))(_k)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -179,3 +179,20 @@ extern "C" __global__ void probe_lds(const float *in, float *out, int *hist) {
         reinterpret_cast<uint4 *>(out + 1024)[t] = v;
     }
 }
+
+// deliberately WRONG: the loaded register is used before any s_waitcnt covers the load (the hazard recogniser of the simulator must fire;
+// hardware would read the stale register here)
+extern "C" __global__ void probe_missing_wait(const int *in, int *out) {
+    int v;
+    asm volatile("global_load_dword %0, %1, off\n\tv_add_u32 %0, %0, %0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(in + threadIdx.x) : "memory");
+    out[threadIdx.x] = v;
+}
+
+// deliberately WRONG: an LDS-DMA lands 1 KiB per wave in shared memory, and the wave reads it back without waiting for vmcnt
+extern "C" __global__ void probe_lds_dma_race(const float *in, float *out) {
+    __shared__ __attribute__((aligned(16))) float buf[256];
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(in + 4 * threadIdx.x),
+                                     (__attribute__((address_space(3))) void *)buf, 16, 0, 0);
+    out[threadIdx.x] = buf[threadIdx.x];                  // (no wait: the compiler does not track the DMA's destination)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}

@@ -32,8 +32,8 @@ class Launch:
         self.strict = sim.strict
         self.ninst = 0
         self.stats = {} if sim.collect_stats else None     # mnemonic -> executed wave-instructions
-        if kernel.scratch:
-            raise SimError(f"{kernel.name}: uses {kernel.scratch} bytes of scratch (not modelled)")
+        if kernel.scratch > 4096:
+            raise SimError(f"{kernel.name}: {kernel.scratch} bytes of scratch per lane (only spill slots are modelled)")
         if kernel.preload & 0x7F:
             raise SimError("kernarg preload not modelled")
         if kernel.code_props & ~0x8 & 0x7F:
@@ -278,8 +278,15 @@ class Simulator:
             return
         mem.undo = []
         nproc, self.nproc = self.nproc, 1
+        # GFX950SIM_WGSAMPLE=n: only n workgroups of each launch (first, last, and spread in between) -- launches at the benchmark's
+        # own sizes (batch 64: the large-index end of every address computation) for the price of a few workgroups each
+        select = None
+        ns = int(os.environ.get("GFX950SIM_WGSAMPLE", "0"))
+        nwg = grid[0] * grid[1] * grid[2]
+        if ns and nwg > ns:
+            select = sorted({0, nwg - 1} | {int(round(i * (nwg - 1) / max(ns - 1, 1))) for i in range(ns)})[:max(ns, 2)]
         try:
-            self.launch(name, grid, block, lds, raw)
+            self.launch(name, grid, block, lds, raw, select=select)
         finally:
             self.nproc = nproc
         log, mem.undo = mem.undo, None

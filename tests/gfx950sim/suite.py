@@ -50,7 +50,7 @@ CONFIGS = {
     "bottom1x1": ("unet", "bottom1x1", 2, {}, 2e-3, "1x1 bottom level: deferred split-K in front of a conv_s upsampler"),
     "no_tail": ("unet", "c2", 1, {"BNDM_NO_TAIL": "1"}, 2e-3, "fallback: <= 8x8 levels on conv_igemm + gn_small"),
     "no_fused": ("unet", "c2", 1, {"BNDM_NO_FUSED": "1"}, 2e-3, "fallback: no conv_t32 (igemm + materialised GroupNorm everywhere)"),
-    "f32mode": ("unet", "c2f32", 1, {}, 1e-4, "fp32-compute verification mode"),
+    "f32mode": ("unet", "lat256f32", 1, {}, 1e-4, "fp32-compute verification mode (plain FMA kernels: the latent 32-px layout, c2 would be ~10^9 wave-instructions)"),
     "vae16": ("unet", "vae16", 1, {}, 5e-3, "AutoencoderKL decoder, full layout, 16x16 latent"),
     "noise_small32col": ("cases", "noise:small32col", None, {}, 1e-4, "bluenoise_small<W32>, 32-px crop, GBN"),
     "noise_gemm128": ("cases", "noise:gemm128", None, {}, 1e-4, "bluenoise_gemm, 128 px tile permutation + scrambled wn, a shard"),
@@ -126,7 +126,7 @@ def run_config(name, lib=None, work=None, procs=8):
     out_dir = os.path.join(work, name)
     env["EXEC_SIM"] = "1"
     if batch is not None:
-        env["EXEC_BATCH"] = str(batch)
+        env["EXEC_BATCH"] = os.environ.get("SIM_BATCH", str(batch))          # (SIM_BATCH: another batch for the same configuration)
     try:
         out = H.run_script("exec_forward.py", lib, out_dir, out_dir, case, wfile, env=env, mockdir=work)
     except AssertionError as e:

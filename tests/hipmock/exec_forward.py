@@ -394,6 +394,45 @@ def k_conv_t32(L):
         stat_write_into(tmp[:, 0], y.reshape(B, Hh * Ww, a.Cout))
 
 
+class HeadArgs(C.Structure):                       # candidate (tools/experiments/head_conv_kernel.patch): csrc/unet_kernels.hpp struct HeadArgs
+    _fields_ = [("x", C.c_uint64), ("gn_p", C.c_uint64), ("gn_gamma", C.c_uint64), ("gn_beta", C.c_uint64), ("gn_ns", C.c_int),
+                ("gn_HW", C.c_int), ("gn_eps", C.c_float), ("Wgt", C.c_uint64), ("bias", C.c_uint64), ("out", C.c_uint64), ("B", C.c_int),
+                ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("Cout", C.c_int), ("ex", C.c_uint64), ("eda", C.c_float), ("edg", C.c_float),
+                ("eC", C.c_int)]
+
+
+def k_head_conv(L):
+    """contract of head_conv: GroupNorm(32) from the producer's partial sums, log2(e) * SiLU rounded to 16 bits, 3x3 convolution with the
+    packed weights [9 C / 32 K-steps (chunk-major, tap-minor)][8 rows][32 k] (ln 2 folded in), + bias -> fp32 NCHW, or the Euler update"""
+    a = HeadArgs.from_buffer_copy(L["args"][0])
+    B, Hh, Ww, Cc, Co = a.B, a.H, a.W, a.C, a.Cout
+    x = rd16(a.x, B * Hh * Ww * Cc).reshape(B, Hh, Ww, Cc)
+    tot = stat_totals(a.gn_p, B, a.gn_ns, Cc)
+    gam, bet = dev(a.gn_gamma, np.float32, Cc), dev(a.gn_beta, np.float32, Cc)
+    wp = rd16(a.Wgt, 9 * (Cc // 32) * 8 * 32).reshape(Cc // 32, 9, 8, 32)
+    Wd = wp.transpose(2, 0, 3, 1).reshape(8, Cc, 3, 3)[:Co]                      # [co][ci = 32 chunk + k][3][3]
+    Cg = Cc // 32
+    outs = []
+    for b in range(B):
+        g = tot[b].reshape(32, -1, 2).sum(1)
+        n = Cg * a.gn_HW
+        mean = g[:, 0] / n
+        var = np.maximum(g[:, 1] / n - mean * mean, 0)
+        sc = (np.repeat(1.0 / np.sqrt(var + a.gn_eps), Cg) * gam).astype(np.float32)
+        sh = (bet - np.repeat(mean, Cg).astype(np.float32) * sc).astype(np.float32)
+        act = r16(LOG2E * silu(x[b] * sc + sh))
+        outs.append(conv3x3(act, Wd) + (dev(a.bias, np.float32, Co) if a.bias else 0))
+    dd = np.stack(outs).transpose(0, 3, 1, 2)                                     # [B][Co][H][W]
+    if a.ex:
+        xv = dev(a.ex, np.float32, B * a.eC * Hh * Ww).reshape(B, a.eC, Hh, Ww)
+        r = xv + np.float32(a.eda) * dd[:, :a.eC]
+        if Co == 2 * a.eC:
+            r = r + np.float32(a.edg) * dd[:, a.eC:]
+        xv[:] = r
+        return
+    dev(a.out, np.float32, B * Co * Hh * Ww)[:] = dd.ravel()
+
+
 def k_conv_s(L):
     a = TailArgs.from_buffer_copy(L["args"][0])
     TM, NB, D = map(int, re.search(r"conv_sID[^_]*_?Li(\d+)ELi(\d+)ELi(\d+)E", L["sym"]).groups())
@@ -629,7 +668,7 @@ KERNELS = {"conv_f32_kernel": k_conv_f32, "gn_f32_kernel": k_gn_f32, "linear_f32
            "attn_f32_kernel": k_attn_f32, "put_channels_f32_kernel": k_put_channels_f32, "attention_kernel": k_attention, "pointwise_f32_kernel": k_pointwise_f32, "gn_apply_kernel": k_gn_apply, "softmax_rows_kernel": k_softmax_rows,
            "temb_mlp_kernel": k_temb_mlp, "conv_igemm": k_igemm, "splitk_reduce_kernel": k_splitk_reduce, "conv_in_kernel": k_conv_in,
            "gn_stats_kernel": k_gn_stats, "gn_small_kernel": k_gn_small, "gn_finalize2_kernel": k_gn_finalize2, "conv_t32": k_conv_t32, "conv_s": k_conv_s,
-           "iadb_step_kernel": k_iadb_step, "ddim_step_kernel": k_ddim_step}
+           "iadb_step_kernel": k_iadb_step, "ddim_step_kernel": k_ddim_step, "head_conv": k_head_conv}
 
 # what is run: (in, out channels, resolution, block_out_channels / attention levels, batch, mode)
 CASES = {
@@ -645,7 +684,8 @@ CASES = {
     "lat256": (4, 8, 32, ((128, 256, 256), 2, 0), 5, "forward"),       # latent celeba_res256: 64-token attention, ragged batch
     "w64": (3, 6, 64, ((64, 128, 128), 2, 0), 3, "forward"),           # groups of two channels; 64 + 128 = 192-channel concats
     "w256": (3, 6, 32, ((256, 256, 512), 2, 0), 1, "forward"),
-    "w64x4": (3, 6, 64, ((64, 64, 128, 256), 3, 0), 2, "forward"),      # tests/test_gpu_first_level_widths.py's second layout: 8x8 attention
+    "w64x4": (3, 6, 64, ((64, 64, 128, 256), 3, 0), 2, "forward"),
+    "lat256f32": (4, 8, 32, ((128, 256, 256), 2, 0), 1, "forward"),    # the fp32-compute mode at a size the instruction-level simulator can afford      # tests/test_gpu_first_level_widths.py's second layout: 8x8 attention
     "bottom1x1": (3, 6, 32, drive.RES64, 3, "forward"),    # the res64 layout on 32x32 inputs: last level 1x1, deferred split-K in
                                                            # front of a conv_s upsampler (round-3 advisor finding), ragged batch 3
     "c2bf16": (3, 6, 64, drive.RES64, 1, "forward"),       # bf16 storage / MFMA inputs (case name ends in bf16)

@@ -231,3 +231,26 @@ def test_lds_barrier_and_atomics(sim):
     assert np.array_equal(hist, np.bincount((t * 7) & 15, weights=t, minlength=16).astype(np.int32))
     tail = a.buf[pout - a.base + 4096:pout - a.base + 4096 + 512].view(np.uint16)
     assert np.array_equal(tail, hs)
+
+
+def test_hazard_recogniser_fires_on_deliberately_wrong_kernels(sim):
+    """two probes that are WRONG on purpose: a register consumed before any s_waitcnt covers its load, and an LDS-DMA destination read
+    back without the wave's vmcnt wait.  Hardware would compute with stale data (sometimes); the simulator must say so every time."""
+    a = sim.arena
+    v = np.arange(64, dtype=np.int32)
+    sim.strict = False
+    try:
+        sim.mem.set_allocs(a.allocs)
+        pin, pout = a.put(v), a.alloc(256)
+        sim.mem.set_allocs(a.allocs)
+        L = sim.launch("probe_missing_wait", (1, 1, 1), (64, 1, 1), 0, [int(pin).to_bytes(8, "little"), int(pout).to_bytes(8, "little")])
+        assert any("while a load into it is in flight" in h for h in L.hazards), L.hazards
+        x = np.arange(256, dtype=np.float32)
+        pin, pout = a.put(x), a.alloc(1024)
+        sim.mem.set_allocs(a.allocs)
+        L = sim.launch("probe_lds_dma_race", (1, 1, 1), (64, 1, 1), 0, [int(pin).to_bytes(8, "little"), int(pout).to_bytes(8, "little")])
+        assert any("LDS-DMA" in h for h in L.hazards), L.hazards
+        # and the stale data is what was read: zeros, not the values the DMA delivered afterwards
+        assert not np.array_equal(a.get(pout, np.float32, (64,)), x[:64])
+    finally:
+        sim.strict = True
