@@ -75,6 +75,15 @@ def case_steps(cx):
         got = cx.down(po, np.uint8, (2, 100, 3))
         want = SO.export_u8(torch.from_numpy(img.reshape(2, 3, 10, 10)), rounding="round" if rnd else "trunc").reshape(2, 100, 3)
         out[f"export_u8_round{rnd}_bitexact"] = bool(np.array_equal(got, np.asarray(want)))
+    # training-time noise injection: forward blend + regression targets, bit-exact vs the oracle's operation order
+    Bt, per = 3, 4 * 9 * 9                                   # ragged: 324 elements per sample
+    t = [rs.standard_normal((Bt, 4, 9, 9)).astype(np.float32) for _ in range(4)]
+    al, alp = rs.rand(Bt).astype(np.float32), rs.rand(Bt).astype(np.float32)
+    po = [cx.alloc(Bt * per * 4) for _ in range(4)]
+    _lib.check(lib.bndm_iadb_train_targets(cx.up(t[0]), cx.up(t[1]), cx.up(t[2]), cx.up(t[3]), cx.up(al), cx.up(alp), *po, Bt, per, None), "train_targets")
+    want = SO.train_targets(*(torch.from_numpy(v) for v in t), torch.from_numpy(al), torch.from_numpy(alp))
+    for nm, p_, w_ in zip(("x_alpha", "tar1", "tar2", "tar"), po, want):
+        out[f"train_{nm}_bitexact"] = bool(np.array_equal(cx.down(p_, np.float32, t[0].shape), w_.numpy()))
     ok = all(v is True or (isinstance(v, float) and v <= 1e-6) for v in out.values())
     return ok, out
 

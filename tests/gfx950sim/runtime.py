@@ -169,9 +169,11 @@ class Launch:
 
 
 class Simulator:
-    def __init__(self, lib, strict=False, check_bounds=True, max_inst=20_000_000, verbose=False):
-        self.kernels = loader.load_library(lib)
-        self.mem = Memory()
+    def __init__(self, lib=None, strict=False, check_bounds=True, max_inst=20_000_000, verbose=False, kernels=None, mem=None):
+        """lib: a libbndm_hip.so (its code objects are parsed); or `kernels` (loader.load_code_object_file) + `mem` (a core.Memory over a
+        private buffer) for stand-alone launches without the recording runtime"""
+        self.kernels = kernels if kernels is not None else loader.load_library(lib)
+        self.mem = mem if mem is not None else Memory()
         self.strict = strict or os.environ.get("GFX950SIM_STRICT") == "1"      # the first hazard ends the run
         self.check_bounds = check_bounds
         self.max_inst = max_inst

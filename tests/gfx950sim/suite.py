@@ -27,7 +27,7 @@ S4, S4B = _subst("DF16_"), _subst("DF16b")
 # name -> (kind, case, batch, env, bar on rel-L2 / max-abs, what it covers)
 CONFIGS = {
     # ---- fast subset (default CPU suite) ------------------------------------------------------------------------------
-    "steps": ("cases", "steps", None, {}, 0.0, "iadb_step x2, ddim_step, export_u8 x2: bit-exact"),
+    "steps": ("cases", "steps", None, {}, 0.0, "iadb_step x2, ddim_step, export_u8 x2, iadb_train_targets: bit-exact"),
     "noise_small64": ("cases", "noise:small64", None, {}, 1e-4, "bluenoise_small<W16> + finish, B=2 64 px"),
     "lat_t32x4": ("unet", "lat256", 1, {"GFX950SIM_SUBST": S4}, 2e-3,
                   "latent celeba_res256 layout (128,256,256) at 32 px: conv_t32 4-wave TH=16 / TH=8 (substituted), conv_s incl. "
@@ -137,8 +137,10 @@ def run_config(name, lib=None, work=None, procs=8):
     m = re.search(r"OK simulated (\d+) launches; output rms [0-9.]+; hazards (\d+)", out)
     ninst = sum(int(x) for x in re.findall(r"launches\s+(\d+) wave-instructions", out))
     hz = int(m.group(2)) if m else -1
+    import hashlib
     return dict(name=name, ok=bool(m) and hz == 0 and rel <= bar, value=rel, bar=bar, hazards=hz, launches=int(m.group(1)) if m else 0,
-                wave_instructions=ninst, seconds=round(time.time() - t0, 1), detail=out[-1500:], what=what)
+                wave_instructions=ninst, seconds=round(time.time() - t0, 1), detail=out[-1500:], what=what,
+                out_hash=hashlib.sha256(got.numpy().tobytes()).hexdigest()[:16])      # equal hashes = bit-identical results
 
 
 def main():
@@ -159,7 +161,7 @@ def main():
         r = run_config(n, lib, a.work, a.procs)
         v = r.get("value")
         print(f"{'PASS' if r['ok'] else 'FAIL'}  {n:18s} value {v if v is None else format(v, '.3e')} (bar {r.get('bar')})  hazards {r.get('hazards')}  "
-              f"{r.get('launches', 0)} launches  {r.get('wave_instructions', 0)} wave-instructions  {r['seconds']} s   -- {r['what']}", flush=True)
+              f"{r.get('launches', 0)} launches  {r.get('wave_instructions', 0)} wave-instructions  {r['seconds']} s  out {r.get('out_hash', '-')}   -- {r['what']}", flush=True)
         if not r["ok"]:
             bad += 1
             print("      " + str(r.get("detail"))[-2500:].replace("\n", "\n      "), flush=True)

@@ -53,15 +53,11 @@ def sim(tmp_path_factory):
     co = str(tmp_path_factory.mktemp("probe") / "probe.co")
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "--cuda-device-only", "-c", os.path.join(HERE, "gfx950sim", "probe.hip"), "-o", co],
                    check=True, capture_output=True)
-    s = Simulator.__new__(Simulator)
-    Simulator.__init__(s, None) if False else None
-    # a Simulator without a library: kernels of the probe object, memory = the arena
-    s.kernels = loader.load_code_object_file(co)
-    s.arena = Arena()
-    s.mem = Memory(s.arena.base, s.arena.buf.size)
-    s.strict, s.check_bounds, s.max_inst, s.verbose = True, True, 5_000_000, False
-    s.collect_stats, s.stats, s.order, s.nproc = False, [], 0, 1
-    s.log, s.hazards, s.skip, s._tiny, s.subst, s.reference, s.diffs = [], [], set(), set(), [], None, []
+    # a Simulator without a library: the probe object's kernels, memory = the arena
+    arena = Arena()
+    s = Simulator(kernels=loader.load_code_object_file(co), mem=Memory(arena.base, arena.buf.size), strict=True, max_inst=5_000_000)
+    s.arena = arena
+    s.nproc = 1
     return s
 
 
