@@ -313,9 +313,15 @@ class Simulator:
                 o = (a[sel] - starts[wi])
                 sv, rv = sim_vals[sel], ref_vals[sel]
                 line = f"   allocation {int(starts[wi]):#x} (+{int(o.min())}..{int(o.max())}, {int(sel.sum())} bytes): {int((sv != rv).sum())} differ"
-                if (sv != rv).any() and sel.sum() % 4 == 0 and (np.diff(o) == 1).all():
-                    for dt in (np.float16, np.float32):
-                        x, y = sv.view(dt).astype(np.float64), rv.view(dt).astype(np.float64)
+                if (sv != rv).any():
+                    # as 16-bit / 32-bit floats over the aligned elements whose bytes were all stored (the stored set need not be contiguous)
+                    for dt, nb in ((np.float16, 2), (np.float32, 4)):
+                        i0 = np.nonzero((o[:o.size - nb + 1] % nb == 0) & (o[nb - 1:] - o[:o.size - nb + 1] == nb - 1))[0]
+                        if i0.size == 0:
+                            continue
+                        gi = i0[:, None] + np.arange(nb)
+                        x = np.ascontiguousarray(sv[gi]).view(dt).ravel().astype(np.float64)
+                        y = np.ascontiguousarray(rv[gi]).view(dt).ravel().astype(np.float64)
                         fin = np.isfinite(x) & np.isfinite(y)
                         rel = np.linalg.norm((x - y)[fin]) / max(np.linalg.norm(y[fin]), 1e-30)
                         line += f" | as {np.dtype(dt).name}: rel-L2 {rel:.3e}, max|d| {np.abs(x - y)[fin].max() if fin.any() else 0:.3e}, non-finite {int((~fin).sum())}"
