@@ -8,6 +8,7 @@
 #   tools/lib_v15.so  head_euler_step.patch                     IADB Euler update in the head launch's epilogue        bit-equal loop by construction
 #   tools/lib_v16.so  conv_t32_nco64_small_batch.patch          64-channel n-tiles for small-batch handles (BNDM_NCO64_MAX, off by default)
 #   tools/lib_v17.so  head_conv_kernel.patch                    dedicated head kernel + Euler epilogue (supersedes v15)
+#   tools/lib_v18.so  conv_s16_small_grids.patch                16-channel conv_s n-tiles for under-filled grids (conv1 of the 2x2 / 4x4 ResnetBlocks)
 #   tools/lib_lanes.so lanes.patch                              bndm_unet_set_lanes (host side only: same kernels)
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); T=$(mktemp -d); mkdir -p $T/bndm_amd $T/include
@@ -25,5 +26,6 @@ one round4_pairstats_sumsfirst_th32.patch lib_v8.so
 one head_euler_step.patch lib_v15.so
 one conv_t32_nco64_small_batch.patch lib_v16.so
 one head_conv_kernel.patch lib_v17.so
+one conv_s16_small_grids.patch lib_v18.so
 one lanes.patch lib_lanes.so
 rm -rf $T; sha256sum $R/bndm_amd/libbndm_hip.so $R/tools/lib_*.so

@@ -29,6 +29,10 @@ import json,sys
 d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}; print(d['value'], 'images/s;', r.get('ms_per_forward_total'), 'ms per forward,', r.get('launches_total'), 'launches')")
 done
 (cd /tmp/v16 && BNDM_NCO64_MAX=256 timeout 900 python -m pytest tests/test_gpu_benched.py tests/test_gpu_unet.py -m gpu -q -x 2>&1 | tail -3)
+echo "== v18 (conv_s16: 16-channel n-tiles for the conv1 launches of the 2x2 / 4x4 levels): accuracy + A/B on c2, then c5"
+timeout 900 python tools/ab_libs.py --rounds 2 --acc bndm_amd/libbndm_hip.so tools/lib_v18.so "tools/lib_v18.so@BNDM_TAIL_N16_MAX=256" 2>&1 | tail -10
+mkdir -p /tmp/v18 && cp -r bndm_amd tests oracle include bluenoise utils.py iadb_bn.py ddim_diffusers.py latent_iadb_bn_diffusers.py input_args.py pytest.ini __graft_entry__.py bench.py /tmp/v18/ 2>/dev/null && cp tools/lib_v18.so /tmp/v18/bndm_amd/libbndm_hip.so
+(cd /tmp/v18 && timeout 600 python bench.py --config c5 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300; timeout 900 python -m pytest tests/test_gpu_tail.py tests/test_gpu_benched.py -m gpu -q -x 2>&1 | tail -3)
 echo "== v17 (dedicated head kernel + Euler epilogue, supersedes v15): the loop / head tests of tests/ on the candidate, then a timed A/B"
 mkdir -p /tmp/v17 && cp -r bndm_amd tests oracle include bluenoise utils.py iadb_bn.py ddim_diffusers.py latent_iadb_bn_diffusers.py input_args.py pytest.ini __graft_entry__.py bench.py /tmp/v17/ 2>/dev/null && cp tools/lib_v17.so /tmp/v17/bndm_amd/libbndm_hip.so
 (cd /tmp/v17 && timeout 1200 python -m pytest tests/test_gpu_steps.py tests/test_gpu_tail.py tests/test_gpu_benched.py tests/test_gpu_unet.py tests/test_gpu_cli.py -m gpu -q -x 2>&1 | tail -4)

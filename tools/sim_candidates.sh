@@ -3,10 +3,10 @@
 # must reproduce the oracle on the instruction-level simulator (tests/gfx950sim) with zero hazards -> profiles/<tag>_sim_candidates.log.
 # Equal `out` hashes = bit-identical results: the candidates that claim bit-identity by construction (v9, v12, v13) must print the
 # product's hash for the same configuration; v17's fused loop must print the hash of its own step-by-step form.
-#   usage:  bash tools/sim_candidates.sh r06 [name ...]        (default: every candidate; names: v9 v12 v13 v15 v8 v16 v17 lanes)
+#   usage:  bash tools/sim_candidates.sh r06 [name ...]        (default: every candidate; names: v9 v12 v13 v15 v8 v16 v17 v18 lanes)
 tag=${1:-rXX}; shift
 R=$(cd "$(dirname "$0")/.." && pwd); cd $R
-names=${@:-v9 v12 v13 v15 v8 v16 v17 lanes}
+names=${@:-v9 v12 v13 v15 v8 v16 v17 v18 lanes}
 log=profiles/${tag}_sim_candidates.log
 W=${WORK:-/tmp/gfx950sim_work_cand}
 run() { python -m tests.gfx950sim.suite --procs ${PROCS:-8} --work $W "$@" 2>&1 | grep -v "^library" ; }
@@ -30,6 +30,7 @@ for n in $names; do
     v17) run --lib $lib c2 c2_iadb_loop w64 c2_bf16_t32x4 c5 c4 lat256
          echo "## the same loop with BNDM_NO_STEP_FUSION=1 (separate iadb_step launch): must print the fused loop's hash"
          BNDM_NO_STEP_FUSION=1 run --lib $lib c2_iadb_loop ;;
+    v18) run --lib $lib c2 c5 c2_bf16_t32x4 bottom1x1 ;;                     # conv_s16 on the conv1 launches of the 2x2 / 4x4 levels
     lanes) echo "## the in-engine IADB loop as 2 chains of launches (batch 2, one sample per chain); product at batch 2 for the hash:"
          SIM_BATCH=2 run c2_iadb_loop
          EXEC_LANES=2 SIM_BATCH=2 run --lib $lib c2_iadb_loop ;;
