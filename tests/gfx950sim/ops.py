@@ -654,15 +654,9 @@ def _perm(s0, s1, sel):
 
 
 def _ffbh(a):
-    out = np.full(64, M32, U32)
-    nz = a != 0
-    lg = np.zeros(64, np.int64)
-    lg[nz] = np.floor(np.log2(a[nz].astype(F64))).astype(np.int64)
-    # guard against rounding at powers of two minus one
-    lg[nz] = np.where((a[nz].astype(U64) >> lg[nz].astype(U64)) > 1, lg[nz] + 1, lg[nz])
-    lg[nz] = np.where((a[nz].astype(U64) >> lg[nz].astype(U64)) == 0, lg[nz] - 1, lg[nz])
-    out[nz] = (31 - lg[nz]).astype(U32)
-    return out
+    """leading zeros of a 32-bit value (-1 for 0): frexp of the exact float64 gives the bit length"""
+    _, e = np.frexp(a.astype(F64))
+    return np.where(a != 0, (32 - e).astype(np.int64), -1).astype(np.int64).astype(U32)
 
 
 def _popc(a):
