@@ -6,7 +6,6 @@ oracle/ -- the same comparisons tests/test_gpu_steps.py and tests/test_gpu_noise
 
 Prints one JSON line per case: {"case":, "ok":, "launches":, "wave_instructions":, "hazards":, ...}.  (UNet / VAE / sampling
 loop cases run through tests/hipmock/exec_forward.py with EXEC_SIM=1, which shares its set-up with the host-side replay.)"""
-import ctypes as C
 import json
 import os
 import sys

@@ -11,7 +11,7 @@ import re
 
 import numpy as np
 
-from .core import (ACC0, BARRIER, ENDPGM, EXEC, F16, F32, F64, I16, I32, I64, LANE, M0, M32, M64, U8, U16, U32, U64, VCC, Opnd,
+from .core import (BARRIER, ENDPGM, EXEC, F16, F32, F64, I16, I32, I64, LANE, M0, M32, M64, U8, U16, U32, U64, VCC, Opnd,
                    Pending, SimError, bool_to_mask, const_bits, full, full64, mask_to_bool, parse_reg, sx)
 
 BUILDERS = {}

@@ -11,7 +11,7 @@ import time
 import numpy as np
 
 from . import loader
-from .core import (BARRIER, ENDPGM, EXEC, M32, M64, U8, U32, Memory, SimError, Wave, Workgroup)
+from .core import BARRIER, M32, U8, U32, Memory, SimError, Wave, Workgroup
 from .ops import compile_inst
 
 HIDDEN_OK = {"hidden_block_count_x", "hidden_block_count_y", "hidden_block_count_z", "hidden_group_size_x", "hidden_group_size_y",

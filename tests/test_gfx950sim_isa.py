@@ -4,7 +4,6 @@ permutes, LDS transposition with a barrier and atomics, and MFMA with the fragme
 /opt/skills/guides/cdna_hip_programming.md section 3 -- are compiled here by hipcc for gfx950 and executed on the simulator;
 whatever instructions the compiler picked (DPP, ds_bpermute, permlane swaps, SDWA, v_div_scale / fmas / fixup, v_rcp_iflag +
 v_mul_hi corrections, v_perm, ...) must produce the defined result.  None of this repository's kernels is involved."""
-import ctypes as C
 import os
 import shutil
 import subprocess
