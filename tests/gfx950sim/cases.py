@@ -130,6 +130,11 @@ def case_noise(cx, which):
         # a shard of the same global batch (SURVEY 8e caveat 1): samples 1..2 of 4 equal the full result's rows
         full = NO.get_noise_v2(x, Lh, a, "gaussianBN", "test")
         cmp("shard", _noise(cx, Lh, pL, x, a, 128, 0, 2, 4, 1, 2), [f[1:3] for f in full])
+    elif which in ("gemm64_b22", "gemm64_b64"):     # 64 px at 66 / 192 columns: bluenoise_gemm<NT=2> / <NT=3> (c2's own call: B = 64)
+        Bn = 22 if which.endswith("b22") else 64
+        z = rs.standard_normal((Bn, 3, 64, 64)).astype(np.float32)
+        a = np.linspace(0.0, 1.0, Bn).astype(np.float32)
+        cmp("blend", _noise(cx, Lh, pL, z, a, 64, 0, 0, Bn, 0, Bn), NO.get_noise_v2(z, Lh, a, "gaussianBN", "test"))
     elif which == "dense64":        # l_dense = 1: the reference's semantics for an arbitrary matrix
         z = rs.standard_normal((2, 3, 64, 64)).astype(np.float32)
         a = np.array([0.5, 0.75], np.float32)

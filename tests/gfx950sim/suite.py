@@ -55,6 +55,8 @@ CONFIGS = {
     "noise_small32col": ("cases", "noise:small32col", None, {}, 1e-4, "bluenoise_small<W32>, 32-px crop, GBN"),
     "noise_gemm128": ("cases", "noise:gemm128", None, {}, 1e-4, "bluenoise_gemm, 128 px tile permutation + scrambled wn, a shard"),
     "noise_dense64": ("cases", "noise:dense64", None, {}, 1e-4, "l_dense = 1"),
+    "noise_gemm64_b22": ("cases", "noise:gemm64_b22", None, {}, 1e-4, "bluenoise_gemm<NT=2>: 66 columns"),
+    "noise_gemm64_b64": ("cases", "noise:gemm64_b64", None, {}, 1e-4, "bluenoise_gemm<NT=3>: 192 columns -- c2's own noise call (B = 64, 64 px)"),
 }
 FAST = ("steps", "noise_small64", "lat_t32x4")
 
