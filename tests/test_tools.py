@@ -41,3 +41,18 @@ def test_overlap_tool_on_a_synthetic_trace(tmp_path):
     assert lines["conv_s"][1] == "1"
     two = [ln for ln in out.splitlines() if ln.startswith("distinct queues")][0]
     assert "2:  57.1%" in two                                                    # 80 us of 140
+
+
+def test_no_bit_cast_of_a_vector_element_in_the_kernels():
+    """With this toolchain (clang 22 of ROCm 7.2) `__builtin_bit_cast(T, vec[e])` on an ext-vector ELEMENT reads element 0 -- four
+    ds_bpermute of different data fold into one (found on the instruction-level simulator in round 6, reduced case in
+    profiles/r06_README.md).  Kernel sources must go through a scalar temporary."""
+    import glob
+    import re
+    pat = re.compile(r"__builtin_bit_cast\(\s*[\w ]+,\s*\w+\s*(\[[^\]]+\]\s*)+\)")
+    hits = []
+    for f in glob.glob(os.path.join(ROOT, "bndm_amd", "csrc", "*.h*")):
+        for i, ln in enumerate(open(f), 1):
+            if pat.search(ln.split("//")[0]):
+                hits.append(f"{os.path.basename(f)}:{i}: {ln.strip()}")
+    assert not hits, "bit_cast of a subscripted value (vector element?): use a scalar temporary\n" + "\n".join(hits)
