@@ -41,6 +41,7 @@ CONFIGS = {
     "c3_ddim_loop": ("unet", "c3loop", 1, {"EXEC_MAX_BATCH": "64"}, 3e-3, "church_res64 3->3: two steps of the in-engine DDIM loop"),
     "c2_iadb_loop": ("unet", "c2loop", 1, {"EXEC_MAX_BATCH": "64"}, 2e-3, "two steps of the in-engine IADB loop with snapshots"),
     "c4": ("unet", "c4", 1, {"EXEC_MAX_BATCH": "32", "GFX950SIM_SUBST": S4}, 2e-3, "celeba_res128 3->6 (7 levels)"),
+    "c4_b1_handle": ("unet", "c4", 1, {"EXEC_MAX_BATCH": "1"}, 2e-3, "celeba_res128 on a batch-1 handle: 128-pixel tiles everywhere (128 GroupNorm slabs at 128x128)"),
     "c5": ("unet", "c5", 1, {"EXEC_MAX_BATCH": "8"}, 2e-3, "latent 4->8 at c5's per-GPU batch handle"),
     "cond": ("unet", "cond", 1, {}, 2e-3, "conditional (super-resolution) sampler, two steps"),
     "lat256": ("unet", "lat256", 2, {}, 2e-3, "latent celeba_res256 layout, ragged batch"),

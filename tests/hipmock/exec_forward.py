@@ -365,19 +365,6 @@ def k_conv_t32(L):
             acc += dev(a.bias, np.float32, a.Cout)
         outs.append(acc)
     y = np.stack(outs)
-    if head and (a.out_nchw32 & 2):
-        # candidate contract (tools/experiments/head_euler_step.patch): the head applies the IADB Euler update to the sampler state
-        # instead of storing d -- resid = x (fp32 NCHW), temb_bstride / temb_off = the bits of da / dg, bit 2 = two-headed output
-        da = np.frombuffer(np.int32(a.temb_bstride).tobytes(), np.float32)[0]
-        dg = np.frombuffer(np.int32(a.temb_off).tobytes(), np.float32)[0]
-        Cx = a.Cout // 2 if a.out_nchw32 & 4 else a.Cout
-        xv = dev(a.resid, np.float32, B * Cx * Hh * Ww).reshape(B, Cx, Hh, Ww)
-        dd = y.transpose(0, 3, 1, 2)
-        r = xv + da * dd[:, :Cx]
-        if a.out_nchw32 & 4:
-            r = r + dg * dd[:, Cx:2 * Cx]
-        xv[:] = r
-        return
     if head:
         dev(a.out, np.float32, B * a.Cout * Hh * Ww)[:] = y.transpose(0, 3, 1, 2).ravel()
         return

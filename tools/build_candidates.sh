@@ -5,9 +5,8 @@
 #   tools/lib_v12.so  conv_t32_scalar_chunks_on_product.patch   chunk descriptors from scalar kernel args  bit-identical by construction
 #   tools/lib_v13.so  conv_t32_first_round_write_back.patch     write-back stores except in the last round bit-identical by construction
 #   tools/lib_v8.so   round4_pairstats_sumsfirst_th32.patch     pair-granular sums, sums-first prologue, conv_t32<TH=32> behind BNDM_TH32_MIN
-#   tools/lib_v15.so  head_euler_step.patch                     IADB Euler update in the head launch's epilogue        bit-equal loop by construction
 #   tools/lib_v16.so  conv_t32_nco64_small_batch.patch          64-channel n-tiles for small-batch handles (BNDM_NCO64_MAX, off by default)
-#   tools/lib_v17.so  head_conv_kernel.patch                    dedicated head kernel + Euler epilogue (supersedes v15)
+#   tools/lib_v17.so  head_conv_kernel.patch                    dedicated head kernel + Euler epilogue (bit-equal loop; replaced round 5's head_euler_step.patch)
 #   tools/lib_v18.so  conv_s16_small_grids.patch                16-channel conv_s n-tiles for under-filled grids (conv1 of the 2x2 / 4x4 ResnetBlocks)
 #   tools/lib_lanes.so lanes.patch                              bndm_unet_set_lanes (host side only: same kernels)
 set -e
@@ -23,7 +22,6 @@ one conv_t32_shortcut_stages.patch lib_v9.so
 one conv_t32_scalar_chunks_on_product.patch lib_v12.so
 one conv_t32_first_round_write_back.patch lib_v13.so
 one round4_pairstats_sumsfirst_th32.patch lib_v8.so
-one head_euler_step.patch lib_v15.so
 one conv_t32_nco64_small_batch.patch lib_v16.so
 one head_conv_kernel.patch lib_v17.so
 one conv_s16_small_grids.patch lib_v18.so

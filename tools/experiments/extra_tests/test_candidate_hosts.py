@@ -33,15 +33,15 @@ def test_kernel_only_candidates_keep_the_host_side(name, scenario, tmp_path):
     assert [r["calls"] for r in got] == [r["calls"] for r in want]
 
 
-@pytest.mark.parametrize("scenario,flags,cout", [("c2", 7, 6), ("c5", 7, 8), ("cond", 3, 3)])
-def test_euler_step_in_the_head_launch(scenario, flags, cout, tmp_path):
-    """lib_v15: no iadb_step launch in the in-engine loop; the head launch carries x, da, dg and the flag bits
-    (FusedArgs offsets: temb_bstride 152, temb_off 156, resid 160, out_nchw32 176, Cout 204); forwards outside the loop unchanged"""
-    lines = H.run_scenario(lib("lib_v15.so"), scenario, str(tmp_path))
+@pytest.mark.parametrize("scenario,cout", [("c2", 6), ("c5", 8), ("cond", 3)])
+def test_euler_step_in_the_head_launch(scenario, cout, tmp_path):
+    """lib_v17 (head_conv_kernel.patch): no iadb_step launch in the in-engine loop; the head_conv launch carries the sampler state and the
+    step's da / dg (HeadArgs offsets: Cout 88, ex 96, eda 104, edg 108, eC 112); forwards outside the loop store d (ex == 0)"""
+    lines = H.run_scenario(lib("lib_v17.so"), scenario, str(tmp_path))
     H.check_pointers(lines)
     for mark, body in H.stages(lines):
         ls = [H.parse_launch(x) for x in body if x.startswith("launch ")]
-        heads = [d for d in ls if d["name"] == "conv_t32" and "Li32ELi0E" in d["sym"]]
+        heads = [d for d in ls if d["name"] == "head_conv"]
         if mark.startswith("sample_iadb"):
             x = int([ln for ln in body if ln.startswith("malloc")][0].split()[1], 16)
             assert not [d for d in ls if d["name"] == "iadb_step_kernel"]
@@ -49,14 +49,15 @@ def test_euler_step_in_the_head_launch(scenario, flags, cout, tmp_path):
             assert len(heads) == steps
             for s, d in enumerate(heads):
                 a = d["args"][0]
-                da, dg = struct.unpack_from("<ff", a, 152)
-                resid, = struct.unpack_from("<Q", a, 160)
-                fl, = struct.unpack_from("<i", a, 176)
-                co, = struct.unpack_from("<i", a, 204)
-                assert resid == x and fl == flags and co == cout
+                assert len(a) == 120
+                co, = struct.unpack_from("<i", a, 88)
+                ex, = struct.unpack_from("<Q", a, 96)
+                da, dg = struct.unpack_from("<ff", a, 104)
+                ec, = struct.unpack_from("<i", a, 112)
+                assert ex == x and co == cout and ec == (cout if scenario == "cond" else cout // 2)
                 assert da == struct.unpack("<f", struct.pack("<f", -1.0 / steps))[0] and dg == struct.unpack("<f", struct.pack("<f", -0.5 / steps))[0]
         elif mark.startswith("forward"):
-            assert len(heads) == 1 and struct.unpack_from("<i", heads[0]["args"][0], 176)[0] == 1
+            assert len(heads) == 1 and struct.unpack_from("<Q", heads[0]["args"][0], 96)[0] == 0
 
 
 # ---- whole loops replayed on the CPU through a candidate's own launch list (tests/hipmock/exec_forward.py) vs the oracle ----
@@ -95,8 +96,8 @@ def _replay(libname, case, tmp_path, env=None):
 
 
 def test_euler_step_candidate_loop_equals_the_oracle(tmp_path):
-    """lib_v15: the head launch's new contract (x updated in place, no iadb_step launch) replayed end to end"""
-    out = _replay("lib_v15.so", "c2loop", tmp_path)
+    """lib_v17: the head_conv launch's contract (x updated in place, no iadb_step launch) replayed end to end through the numpy models"""
+    out = _replay("lib_v17.so", "c2loop", tmp_path)
     base = _replay("../bndm_amd/libbndm_hip.so", "c2loop", tmp_path)
     count = lambda o: int(o.split("replayed")[1].split()[0])
     assert count(out) == count(base) - 2                     # one launch fewer per step

@@ -9,10 +9,6 @@ echo "== A/B, two interleaved rounds: shipped | v9 staged 1x1 chunks | v12 scala
 timeout 1500 python tools/ab_libs.py --rounds 2 --acc bndm_amd/libbndm_hip.so tools/lib_v9.so tools/lib_v12.so tools/lib_v13.so 2>&1 | tail -16
 echo "== v8 (round-4 patch: pair-granular sums, sums-first prologue; conv_t32<TH=32> only with BNDM_TH32_MIN): accuracy + A/B"
 timeout 1200 python tools/ab_libs.py --rounds 2 --acc bndm_amd/libbndm_hip.so tools/lib_v8.so "tools/lib_v8.so@BNDM_TH32_MIN=256" 2>&1 | tail -12
-echo "== v15 (Euler update in the head launch): the loop tests of tests/ on the candidate, then a timed A/B of the whole loop"
-mkdir -p /tmp/v15 && cp -r bndm_amd tests oracle include bluenoise utils.py iadb_bn.py ddim_diffusers.py latent_iadb_bn_diffusers.py input_args.py pytest.ini __graft_entry__.py bench.py /tmp/v15/ 2>/dev/null && cp tools/lib_v15.so /tmp/v15/bndm_amd/libbndm_hip.so
-(cd /tmp/v15 && timeout 900 python -m pytest tests/test_gpu_steps.py tests/test_gpu_tail.py tests/test_gpu_benched.py tests/test_gpu_cli.py -m gpu -q -x 2>&1 | tail -4)
-timeout 900 python tools/ab_libs.py --rounds 2 --full bndm_amd/libbndm_hip.so tools/lib_v15.so 2>&1 | tail -8
 echo "== c5 (latent UNet, B = 8 per GPU) under the EXISTING switches: is a batch-size heuristic between tested code paths worth anything?"
 for e in "" "BNDM_NO_TAIL=1" "BNDM_TH16_MIN=1"; do
   echo -n "-- c5 ${e:-default}:  "
@@ -33,7 +29,7 @@ echo "== v18 (conv_s16: 16-channel n-tiles for the conv1 launches of the 2x2 / 4
 timeout 900 python tools/ab_libs.py --rounds 2 --acc bndm_amd/libbndm_hip.so tools/lib_v18.so "tools/lib_v18.so@BNDM_TAIL_N16_MAX=256" 2>&1 | tail -10
 mkdir -p /tmp/v18 && cp -r bndm_amd tests oracle include bluenoise utils.py iadb_bn.py ddim_diffusers.py latent_iadb_bn_diffusers.py input_args.py pytest.ini __graft_entry__.py bench.py /tmp/v18/ 2>/dev/null && cp tools/lib_v18.so /tmp/v18/bndm_amd/libbndm_hip.so
 (cd /tmp/v18 && timeout 600 python bench.py --config c5 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300; timeout 900 python -m pytest tests/test_gpu_tail.py tests/test_gpu_benched.py -m gpu -q -x 2>&1 | tail -3)
-echo "== v17 (dedicated head kernel + Euler epilogue, supersedes v15): the loop / head tests of tests/ on the candidate, then a timed A/B"
+echo "== v17 (dedicated head kernel + Euler epilogue, replaced round 5's v15): the loop / head tests of tests/ on the candidate, then a timed A/B"
 mkdir -p /tmp/v17 && cp -r bndm_amd tests oracle include bluenoise utils.py iadb_bn.py ddim_diffusers.py latent_iadb_bn_diffusers.py input_args.py pytest.ini __graft_entry__.py bench.py /tmp/v17/ 2>/dev/null && cp tools/lib_v17.so /tmp/v17/bndm_amd/libbndm_hip.so
 (cd /tmp/v17 && timeout 1200 python -m pytest tests/test_gpu_steps.py tests/test_gpu_tail.py tests/test_gpu_benched.py tests/test_gpu_unet.py tests/test_gpu_cli.py -m gpu -q -x 2>&1 | tail -4)
 timeout 900 python tools/ab_libs.py --rounds 2 --full bndm_amd/libbndm_hip.so tools/lib_v17.so 2>&1 | tail -8
