@@ -26,7 +26,7 @@ for n in $names; do
          BNDM_NCO64_MAX=256 run --lib $lib c5
          echo "## c2 handle (max_batch 64), BNDM_NCO64_MAX=1000000: <TH=16, N=64>"
          BNDM_NCO64_MAX=1000000 run --lib $lib c2 ;;
-    v17) run --lib $lib c2 c2_iadb_loop w64 c2_bf16_t32x4 c5 c4 lat256
+    v17) run --lib $lib c2 c2_iadb_loop w64 c2_bf16_t32x4 c5 c4 c4_b1_handle lat256
          echo "## the same loop with BNDM_NO_STEP_FUSION=1 (separate iadb_step launch): must print the fused loop's hash"
          BNDM_NO_STEP_FUSION=1 run --lib $lib c2_iadb_loop ;;
     v18) run --lib $lib c2 c5 c2_bf16_t32x4 bottom1x1 ;;                     # conv_s16 on the conv1 launches of the 2x2 / 4x4 levels
