@@ -67,6 +67,10 @@ def case_steps(cx):
     x0 = np.clip((3 * x - s1at * eps) / sat, np.float32(-1), np.float32(1))          # ddim_diffusers.py:680 (eps-prediction, eta 0)
     want = sap * x0 + s1ap * eps
     out["ddim_step_rel"] = float(np.abs(got - want).max() / np.abs(want).max())
+    px = cx.up(3 * x)                                           # clip <= 0: no clipping of the predicted x0
+    _lib.check(lib.bndm_ddim_step(px, pe, sat, s1at, sap, s1ap, 0.0, x.size, None), "ddim_step")
+    want = sap * ((3 * x - s1at * eps) / sat) + s1ap * eps
+    out["ddim_step_noclip_rel"] = float(np.abs(cx.down(px, np.float32, x.shape) - want).max() / np.abs(want).max())
     img = (rs.standard_normal((2, 3, 100)) * 0.7).astype(np.float32)
     for rnd in (0, 1):
         po = cx.alloc(img.size)

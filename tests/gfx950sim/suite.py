@@ -51,6 +51,8 @@ CONFIGS = {
     "bottom1x1": ("unet", "bottom1x1", 2, {}, 2e-3, "1x1 bottom level: deferred split-K in front of a conv_s upsampler"),
     "no_tail": ("unet", "c2", 1, {"BNDM_NO_TAIL": "1"}, 2e-3, "fallback: <= 8x8 levels on conv_igemm + gn_small"),
     "no_fused": ("unet", "c2", 1, {"BNDM_NO_FUSED": "1"}, 2e-3, "fallback: no conv_t32 (igemm + materialised GroupNorm everywhere)"),
+    "no_gn_small": ("unet", "lat256", 1, {"BNDM_NO_TAIL": "1", "BNDM_NO_GN_SMALL": "1"}, 2e-3, "fallback variant: no gn_small (gn_stats + finalize + apply at <= 8x8)"),
+    "no_defer": ("unet", "lat256", 1, {"BNDM_NO_TAIL": "1", "BNDM_NO_DEFER": "1"}, 2e-3, "fallback variant: split-K sums by splitk_reduce instead of the consumer"),
     "f32mode": ("unet", "lat256f32", 1, {}, 1e-4, "fp32-compute verification mode (plain FMA kernels: the latent 32-px layout, c2 would be ~10^9 wave-instructions)"),
     "vae16": ("unet", "vae16", 1, {}, 5e-3, "AutoencoderKL decoder, full layout, 16x16 latent"),
     "noise_small32col": ("cases", "noise:small32col", None, {}, 1e-4, "bluenoise_small<W32>, 32-px crop, GBN"),
