@@ -32,6 +32,10 @@ CONFIGS = {
     "lat_t32x4": ("unet", "lat256", 1, {"GFX950SIM_SUBST": S4}, 2e-3,
                   "latent celeba_res256 layout (128,256,256) at 32 px: conv_t32 4-wave TH=16 / TH=8 (substituted), conv_s incl. "
                   "64-token attention, igemm downsampler, head"),
+    "deep32_t32x4": ("unet", "deep32", 1, {"GFX950SIM_SUBST": S4, "EXEC_MAX_BATCH": "64"}, 2e-3,
+                     "five levels 32 .. 2 px (128,128,256,256,512), 4x4 attention, handle sized for batch 64 (the benchmark's tile variants): conv_t32 "
+                     "4-wave TH=16 -- the DOMINANT kernel -- and TH=8 (substituted), conv_s<TM=128> / <TM=64> at 8x8 / 4x4 / "
+                     "2x2 incl. stride-2, nearest-2x, shortcut and q|k|v + attention launches, gn_small, igemm downsamplers, conv_in, head"),
     # ---- full suite (tools/sim_suite.sh; RUN_SIM_SLOW=1) ------------------------------------------------------------------
     "c2": ("unet", "c2", 1, {"EXEC_MAX_BATCH": "64"}, 2e-3, "cat_res64 3->6, the handle bench.py builds (conv_s<TM=128>), 8-wave conv_t32"),
     "c2_t32x4": ("unet", "c2", 1, {"EXEC_MAX_BATCH": "64", "GFX950SIM_SUBST": S4}, 2e-3, "... with the DOMINANT 4-wave conv_t32<TH=16> / <TH=8>"),
@@ -61,7 +65,7 @@ CONFIGS = {
     "noise_gemm64_b22": ("cases", "noise:gemm64_b22", None, {}, 1e-4, "bluenoise_gemm<NT=2>: 66 columns"),
     "noise_gemm64_b64": ("cases", "noise:gemm64_b64", None, {}, 1e-4, "bluenoise_gemm<NT=3>: 192 columns -- c2's own noise call (B = 64, 64 px)"),
 }
-FAST = ("steps", "noise_small64", "lat_t32x4")
+FAST = ("steps", "noise_small64", "deep32_t32x4")
 
 
 def expected(case, sd, cfg, out_dir):

@@ -672,6 +672,7 @@ CASES = {
     "w64": (3, 6, 64, ((64, 128, 128), 2, 0), 3, "forward"),           # groups of two channels; 64 + 128 = 192-channel concats
     "w256": (3, 6, 32, ((256, 256, 512), 2, 0), 1, "forward"),
     "w64x4": (3, 6, 64, ((64, 64, 128, 256), 3, 0), 2, "forward"),
+    "deep32": (3, 6, 32, ((128, 128, 256, 256, 512), 3, 1), 1, "forward"),   # five levels 32 .. 2 px, 4x4 attention: every kernel family of c2 at 1/4 of its size
     "lat256f32": (4, 8, 32, ((128, 256, 256), 2, 0), 1, "forward"),    # the fp32-compute mode at a size the instruction-level simulator can afford      # tests/test_gpu_first_level_widths.py's second layout: 8x8 attention
     "bottom1x1": (3, 6, 32, drive.RES64, 3, "forward"),    # the res64 layout on 32x32 inputs: last level 1x1, deferred split-K in
                                                            # front of a conv_s upsampler (round-3 advisor finding), ragged batch 3

@@ -40,10 +40,11 @@ def _check(r):
 
 @pytest.mark.parametrize("name", suite.FAST)
 def test_shipped_machine_code_reproduces_the_oracle(name, workdir):
-    """steps: the Euler / DDIM / export kernels bit-exact; noise_small64: the L.z transform vs the noise oracle (<= 1e-4);
-    lat_t32x4: a whole UNet forward (latent celeba_res256 layout at 32 px, batch 1) in which the 4-wave conv_t32<TH=16> and
-    <TH=8> -- the dominant kernel of the benchmark -- run on the recorded arguments of the 8-wave launches, plus conv_s with
-    attention, conv_in, the igemm downsampler and the head: rel-L2 <= 2e-3 vs oracle/unet_oracle.py, zero hazards"""
+    """steps: the Euler / DDIM / export / training-target kernels bit-exact; noise_small64: the L.z transform vs the noise oracle
+    (<= 1e-4); deep32_t32x4: a whole UNet forward -- five levels from 32 to 2 px with 4x4 attention, batch 1 on a handle sized for
+    batch 64 -- in which the 4-wave conv_t32<TH=16> (the dominant kernel of the benchmark) and <TH=8> run on the recorded arguments
+    of the 8-wave launches, next to conv_s at 8x8 / 4x4 / 2x2 with its stride-2, nearest-2x, shortcut and attention launches, gn_small,
+    conv_in, the igemm downsamplers and the head: rel-L2 <= 2e-3 vs oracle/unet_oracle.py, zero hazards"""
     _check(suite.run_config(name, work=workdir, procs=int(os.environ.get("GFX950SIM_TEST_PROCS", "8"))))
 
 
