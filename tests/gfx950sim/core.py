@@ -197,6 +197,7 @@ class Wave:
         self.ninst = 0
         self.clock = 1000 + 17 * wid
         self.mem = wg.launch.mem
+        self.stats_on = wg.launch.stats is not None          # GFX950SIM_STATS=1: instruction counts, bytes moved, LDS bank cycles
         nscr = (kernel.scratch + 3) // 4
         self.scratch = np.zeros((nscr, 64), U32) if nscr else None      # private segment: register spill slots, per lane
 

@@ -5,7 +5,7 @@ oracle/ as the checker -- on what the simulator computed, and require zero hazar
 flight, out-of-bounds accesses).
 
 This does NOT replace the GPU suite (the simulator's instruction semantics are the author's reading of the ISA, calibrated on
-kernels whose hardware results are on record; time, caches and bank conflicts are not modelled).  It is what can be known about
+kernels whose hardware results are on record; time and caches are not modelled).  It is what can be known about
 device code while no GPU is reachable, and the gate a candidate library passes before it is given GPU minutes.
 
 Default run: the fast subset (about a minute on 8 cores).  RUN_SIM_SLOW=1 adds every configuration of tests/gfx950sim/suite.py

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Gate in front of any GPU minute: a candidate library (tools/lib_*.so, one patch of tools/experiments/ each; tools/build_candidates.sh)
 # must reproduce the oracle on the instruction-level simulator (tests/gfx950sim) with zero hazards -> profiles/<tag>_sim_candidates.log.
-# Equal `out` hashes = bit-identical results: the candidates that claim bit-identity by construction (v9, v12, v13) must print the
+# Equal `out` hashes = bit-identical results: the candidates that claim bit-identity by construction (v9, v12, v19) must print the
 # product's hash for the same configuration; v17's fused loop must print the hash of its own step-by-step form.
-#   usage:  bash tools/sim_candidates.sh r06 [name ...]        (default: every candidate; names: v9 v12 v13 v8 v16 v17 v18 lanes)
+#   usage:  bash tools/sim_candidates.sh r06 [name ...]        (default: every candidate; names: v9 v12 v19 v8 v16 v17 v18 lanes)
 tag=${1:-rXX}; shift
 R=$(cd "$(dirname "$0")/.." && pwd); cd $R
-names=${@:-v9 v12 v13 v8 v16 v17 v18 lanes}
+names=${@:-v9 v12 v19 v8 v16 v17 v18 lanes}
 log=profiles/${tag}_sim_candidates.log
 W=${WORK:-/tmp/gfx950sim_work_cand}
 run() { python -m tests.gfx950sim.suite --procs ${PROCS:-8} --work $W "$@" 2>&1 | grep -v "^library" ; }
@@ -18,7 +18,8 @@ for n in $names; do
   lib=tools/lib_$n.so
   echo "##### $lib  $(sha256sum $lib | cut -c1-64)"
   case $n in
-    v9|v12|v13) run --lib $lib c2_t32x4 ;;                                  # must print the product's c2_t32x4 hash
+    v9|v12) run --lib $lib c2_t32x4 ;;                                      # must print the product's c2_t32x4 hash
+    v19) run --lib $lib c2_t32x4 c5 bottom1x1 c2_bf16_t32x4 lat256 ;;           # must print the product's hashes (profiles/<tag>_sim_suite.log)
     v8)  run --lib $lib c2_t32x4 w64
          echo "## conv_t32<TH=32> (512-pixel tiles, 512 registers, 2 spill slots) on the 64x64 layers: BNDM_TH32_MIN=1"
          BNDM_TH32_MIN=1 run --lib $lib c2 ;;

@@ -25,7 +25,7 @@ def cls_of(m):
 def main():
     st = json.load(open(sys.argv[1]))
     sub = sys.argv[2] if len(sys.argv) > 2 else ""
-    print(f"{'kernel':44s} {'grid':>12s} {'total':>9s} {'mfma':>8s} {'valu':>8s} {'trans':>7s} {'salu':>8s} {'lds':>7s} {'vmem':>6s} {'wait':>7s} {'loadMB':>7s} {'storeMB':>7s}")
+    print(f"{'kernel':44s} {'grid':>12s} {'total':>9s} {'mfma':>8s} {'valu':>8s} {'trans':>7s} {'salu':>8s} {'lds':>7s} {'vmem':>6s} {'wait':>7s} {'loadMB':>7s} {'storeMB':>7s} {'LDScyc':>9s} {'conflict':>8s}")
     for e in st:
         if sub not in e["kernel"]:
             continue
@@ -35,7 +35,8 @@ def main():
         name = re.sub(r"^_ZN4bndm12_GLOBAL__N_1\d+", "", e["kernel"])[:44]
         g = "x".join(str(x) for x in e["grid"])
         print(f"{name:44s} {g:>12s} {sum(c.values()):9d} {c.get('mfma', 0):8d} {c.get('valu', 0):8d} {c.get('trans', 0):7d} {c.get('salu', 0):8d} "
-              f"{c.get('lds', 0):7d} {c.get('vmem', 0):6d} {c.get('wait', 0):7d} {e['bytes'].get('load', 0) / 1e6:7.2f} {e['bytes'].get('store', 0) / 1e6:7.2f}")
+              f"{c.get('lds', 0):7d} {c.get('vmem', 0):6d} {c.get('wait', 0):7d} {e['bytes'].get('load', 0) / 1e6:7.2f} {e['bytes'].get('store', 0) / 1e6:7.2f} "
+              f"{e['bytes'].get('lds_cycles', 0):9d} {100.0 * e['bytes'].get('lds_conflict', 0) / max(e['bytes'].get('lds_cycles', 0), 1):7.1f}%")
 
 
 if __name__ == "__main__":
