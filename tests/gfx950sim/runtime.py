@@ -352,6 +352,9 @@ class Simulator:
             self.stats.append((name, tuple(grid), L.stats, dict(self.mem.counters)))
             self.mem.counters.clear()
         self.log.append((name, tuple(grid), L.ninst, dt, len(L.hazards)))
+        if os.environ.get("GFX950SIM_COVERAGE"):          # one line per executed launch: the kernel that RAN (after substitution)
+            with open(os.environ["GFX950SIM_COVERAGE"], "a") as f:
+                f.write(f"{k.name} {L.ninst} {len(L.hazards)}\n")
         self.hazards.extend(f"{name[:60]}: {h}" for h in L.hazards)
         if self.verbose:
             print(f"[sim] {loader_short(name):40s} grid={tuple(grid)} block={tuple(block)} {L.ninst:9d} wave-insts {dt:6.2f}s hazards={len(L.hazards)}",

@@ -32,7 +32,7 @@ CONFIGS = {
     "lat_t32x4": ("unet", "lat256", 1, {"GFX950SIM_SUBST": S4}, 2e-3,
                   "latent celeba_res256 layout (128,256,256) at 32 px: conv_t32 4-wave TH=16 / TH=8 (substituted), conv_s incl. "
                   "64-token attention, igemm downsampler, head"),
-    "deep32_t32x4": ("unet", "deep32", 1, {"GFX950SIM_SUBST": S4, "EXEC_MAX_BATCH": "64"}, 2e-3,
+    "deep32_t32x4": ("unet", "deep32", 1, {"GFX950SIM_SUBST": S4, "EXEC_MAX_BATCH": "64", "GFX950SIM_STATS": "1"}, 2e-3,
                      "five levels 32 .. 2 px (128,128,256,256,512), 4x4 attention, handle sized for batch 64 (the benchmark's tile variants): conv_t32 "
                      "4-wave TH=16 -- the DOMINANT kernel -- and TH=8 (substituted), conv_s<TM=128> / <TM=64> at 8x8 / 4x4 / "
                      "2x2 incl. stride-2, nearest-2x, shortcut and q|k|v + attention launches, gn_small, igemm downsamplers, conv_in, head"),
@@ -42,6 +42,7 @@ CONFIGS = {
     "c2_t32x4_rev": ("unet", "c2", 1, {"EXEC_MAX_BATCH": "64", "GFX950SIM_SUBST": S4, "GFX950SIM_ORDER": "1"}, 2e-3, "... waves in reverse order"),
     "c2_b2_random": ("unet", "c2", 2, {"GFX950SIM_ORDER": "5"}, 2e-3, "B=2 (conv_s<TM=64>), waves in random order"),
     "c2_bf16_t32x4": ("unet", "c2bf16", 1, {"EXEC_MAX_BATCH": "64", "GFX950SIM_SUBST": S4B}, 1e-2, "bf16 storage / MFMA inputs"),
+    "c2_bf16": ("unet", "c2bf16", 1, {"EXEC_MAX_BATCH": "64"}, 1e-2, "bf16 with the 8-wave conv_t32 variants (what a batch-1 call launches)"),
     "c3_ddim_loop": ("unet", "c3loop", 1, {"EXEC_MAX_BATCH": "64"}, 3e-3, "church_res64 3->3: two steps of the in-engine DDIM loop"),
     "c2_iadb_loop": ("unet", "c2loop", 1, {"EXEC_MAX_BATCH": "64"}, 2e-3, "two steps of the in-engine IADB loop with snapshots"),
     "c4": ("unet", "c4", 1, {"EXEC_MAX_BATCH": "32", "GFX950SIM_SUBST": S4}, 2e-3, "celeba_res128 3->6 (7 levels)"),
@@ -59,6 +60,13 @@ CONFIGS = {
     "no_defer": ("unet", "lat256", 1, {"BNDM_NO_TAIL": "1", "BNDM_NO_DEFER": "1"}, 2e-3, "fallback variant: split-K sums by splitk_reduce instead of the consumer"),
     "f32mode": ("unet", "lat256f32", 1, {}, 1e-4, "fp32-compute verification mode (plain FMA kernels: the latent 32-px layout, c2 would be ~10^9 wave-instructions)"),
     "vae16": ("unet", "vae16", 1, {}, 5e-3, "AutoencoderKL decoder, full layout, 16x16 latent"),
+    # ---- kernel variants no benchmark configuration launches (coverage: every reachable kernel of the library runs at least once) --------
+    "igemm_256x128": ("unet", "big128", 12, {"BNDM_NO_FUSED": "1"}, 2e-3, "conv_igemm's 256x128 3-stage tile (plain + nearest-2x source): B=12 at 64x64x128 = 192 tiles"),
+    "igemm_256x128_bf16": ("unet", "big128bf16", 12, {"BNDM_NO_FUSED": "1"}, 1e-2, "... bf16"),
+    "generic_bf16": ("unet", "w64bf16", 1, {"BNDM_NO_FUSED": "1", "BNDM_NO_TAIL": "1"}, 1e-2, "bf16 instances of the fallback kernels: igemm tiles incl. the 128x32 head, gn_apply, attention_kernel"),
+    "lat_bf16_t32x4": ("unet", "lat256bf16", 1, {"GFX950SIM_SUBST": S4B}, 1e-2, "bf16 conv_t32<TH=8> / 4-wave variants incl. the 32-channel head at 32 px"),
+    "vae16_bf16": ("unet", "vae16bf16", 1, {}, 4e-2, "AutoencoderKL decoder in bf16 (softmax_rows<bf16>; no reference tolerance exists for this mode: the bar is 8x the f16 one)"),
+    "f32mode_loop": ("unet", "loop16f32", 1, {}, 1e-4, "two steps of the in-engine IADB loop in fp32 mode (fill_f32_kernel)"),
     "noise_small32col": ("cases", "noise:small32col", None, {}, 1e-4, "bluenoise_small<W32>, 32-px crop, GBN"),
     "noise_gemm128": ("cases", "noise:gemm128", None, {}, 1e-4, "bluenoise_gemm, 128 px tile permutation + scrambled wn, a shard"),
     "noise_dense64": ("cases", "noise:dense64", None, {}, 1e-4, "l_dense = 1"),
@@ -73,8 +81,8 @@ def expected(case, sd, cfg, out_dir):
     import numpy as np
     import torch
     from oracle import unet_oracle as UO
-    from tests.hipmock.exec_forward import CASES, DA, DDIM, DG, T_IN
-    cin, cout, res, layout, B, mode = CASES[case]
+    from tests.hipmock.exec_forward import CASES, DA, DDIM, DG, SIM_CASES, T_IN
+    cin, cout, res, layout, B, mode = {**CASES, **SIM_CASES}[case]
     load = lambda what: torch.from_numpy(np.load(os.path.join(out_dir, f"exec_{case}_{what}.npy")))
     x = load("x")
     if mode == "vae":
@@ -113,6 +121,20 @@ def run_config(name, lib=None, work=None, procs=8):
     H.build_mock(work)
     t0 = time.time()
     env = dict(env, GFX950SIM_PROCS=str(procs), OMP_NUM_THREADS="4", MKL_NUM_THREADS="4")
+    cov = os.path.join(work, f"coverage_{name}.txt")
+    if os.path.exists(cov):
+        os.remove(cov)
+    env["GFX950SIM_COVERAGE"] = cov
+
+    def kernels_run():
+        out = {}
+        if os.path.exists(cov):
+            for ln in open(cov):
+                k, ni, hz = ln.split()
+                e = out.setdefault(k, [0, 0])
+                e[0] += 1
+                e[1] += int(ni)
+        return out
     if kind == "cases":
         e = dict(os.environ, **env, LD_LIBRARY_PATH=work + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""),
                  HIPMOCK_TRACE=os.path.join(work, f"trace_cases_{name}.txt"), HIPMOCK_KERNARGS=H.kernargs_file(lib, work))
@@ -126,7 +148,8 @@ def run_config(name, lib=None, work=None, procs=8):
         j = json.loads(line)
         vals = [v for k, v in j.items() if isinstance(v, float) and k != "seconds"]
         return dict(name=name, ok=bool(j["ok"]) and r.returncode == 0, value=max(vals) if vals else 0.0, bar=bar, hazards=len(j["hazards"]),
-                    launches=j["launches"], wave_instructions=j["wave_instructions"], seconds=round(time.time() - t0, 1), detail=j, what=what)
+                    launches=j["launches"], wave_instructions=j["wave_instructions"], seconds=round(time.time() - t0, 1), detail=j, what=what,
+                    kernels=kernels_run())
     from tests import test_launch_trace as T
     import torch
     torch.set_num_threads(4)
@@ -137,8 +160,8 @@ def run_config(name, lib=None, work=None, procs=8):
     if batch is not None:
         env["EXEC_BATCH"] = os.environ.get("SIM_BATCH", str(batch))          # (SIM_BATCH: another batch for the same configuration)
     try:
-        out = H.run_script("exec_forward.py", lib, out_dir, out_dir, case, wfile, env=env, mockdir=work)
-    except AssertionError as e:
+        out = H.run_script("exec_forward.py", lib, out_dir, out_dir, case, wfile, env=env, mockdir=work, timeout=3000)
+    except (AssertionError, subprocess.TimeoutExpired) as e:
         return dict(name=name, ok=False, detail=str(e)[-3000:], seconds=round(time.time() - t0, 1), what=what)
     got, want = expected(case, sd, cfg, out_dir)
     rel = float((got - want).double().norm() / want.double().norm())
@@ -149,7 +172,8 @@ def run_config(name, lib=None, work=None, procs=8):
     import hashlib
     return dict(name=name, ok=bool(m) and hz == 0 and rel <= bar, value=rel, bar=bar, hazards=hz, launches=int(m.group(1)) if m else 0,
                 wave_instructions=ninst, seconds=round(time.time() - t0, 1), detail=out[-1500:], what=what,
-                out_hash=hashlib.sha256(got.numpy().tobytes()).hexdigest()[:16])      # equal hashes = bit-identical results
+                out_hash=hashlib.sha256(got.numpy().tobytes()).hexdigest()[:16],      # equal hashes = bit-identical results
+                kernels=kernels_run())
 
 
 def main():
@@ -158,6 +182,7 @@ def main():
     ap.add_argument("--lib")
     ap.add_argument("--procs", type=int, default=8)
     ap.add_argument("--work")
+    ap.add_argument("--coverage", help="write: every kernel of the library and the configurations of this run that executed it")
     ap.add_argument("names", nargs="+")
     a = ap.parse_args()
     names = list(CONFIGS) if a.names == ["all"] else list(FAST) if a.names == ["fast"] else a.names
@@ -166,15 +191,68 @@ def main():
     lib = os.path.abspath(a.lib or H.PRODUCT_LIB)
     print(f"library: {hashlib.sha256(open(lib, 'rb').read()).hexdigest()}  {lib}", flush=True)
     bad = 0
+    ran = {}
     for n in names:
         r = run_config(n, lib, a.work, a.procs)
+        if r["ok"]:
+            for k, (nl, ni) in r.get("kernels", {}).items():
+                ran.setdefault(k, []).append((n, nl, ni))
         v = r.get("value")
         print(f"{'PASS' if r['ok'] else 'FAIL'}  {n:18s} value {v if v is None else format(v, '.3e')} (bar {r.get('bar')})  hazards {r.get('hazards')}  "
               f"{r.get('launches', 0)} launches  {r.get('wave_instructions', 0)} wave-instructions  {r['seconds']} s  out {r.get('out_hash', '-')}   -- {r['what']}", flush=True)
         if not r["ok"]:
             bad += 1
             print("      " + str(r.get("detail"))[-2500:].replace("\n", "\n      "), flush=True)
+    if a.coverage:
+        write_coverage(a.coverage, lib, ran, names)
     sys.exit(1 if bad else 0)
+
+
+# instantiated but not launchable through the library's host code (read off unet_kernels.hip::launch_conv_t / unet_engine.hip)
+UNREACHABLE = {
+    "Li4ELi1ELi1ELi1ELi0ELi4E": "conv_igemm 128x32 tile + NHWC16 epilogue: launch_conv_t instantiates the pair, the engine uses TILE_128x32 only for the NCHW32 head",
+    "Li4ELi1ELi1ELi1ELi2ELi4ELb1E": "table-driven 128x32 head: the head's ConvArgs carries no step table, launch_conv_cfg always picks the generic walk",
+    "Li4ELi2ELi2ELi2ELi1ELi3E": "conv_igemm 256x128 tile + split-K fp32 epilogue: plan_conv splits K only below 192 tiles, where it has already picked 128x128",
+    "gn_finalize_kernel": "superseded by gn_finalize2_kernel: launch_gn_finalize has no caller",
+}
+
+
+def coverage_from_work(work, names):
+    """{kernel: [(configuration, launches, wave-instructions)]} from the coverage_<name>.txt files a run left in its work directory"""
+    ran = {}
+    for n in names:
+        per = {}
+        for ln in open(os.path.join(work, f"coverage_{n}.txt")):
+            k, ni, hz = ln.split()
+            e = per.setdefault(k, [0, 0])
+            e[0] += 1
+            e[1] += int(ni)
+        for k, (nl, ni) in per.items():
+            ran.setdefault(k, []).append((n, nl, ni))
+    return ran
+
+
+def write_coverage(path, lib, ran, names):
+    """every kernel in the library's gfx950 code objects x the PASSING configurations that executed it (hazard-free, result within the bar)"""
+    import hashlib
+    import re
+    from tests.gfx950sim import loader
+    ks = loader.load_library(lib)
+    short = lambda k: re.sub(r"^_ZN4bndm12_GLOBAL__N_1\d+|^_ZN12_GLOBAL__N_1\d+", "", k)
+    with open(path, "w") as f:
+        f.write(f"# kernels of {lib} (sha256 {hashlib.sha256(open(lib, 'rb').read()).hexdigest()}) executed on the instruction-level simulator\n")
+        f.write(f"# by the PASSING configurations of this run ({len(names)}: {' '.join(names)})\n")
+        f.write(f"# {sum(1 for k in ks if k in ran)} of {len(ks)} kernels executed\n")
+        f.write(f"# {'kernel':96s} launches  wave-instructions  configurations\n")
+        for k in sorted(ks, key=short):
+            e = ran.get(k)
+            if e:
+                f.write(f"{short(k)[:98]:98s} {sum(x[1] for x in e):8d} {sum(x[2] for x in e):18d}  {' '.join(x[0] for x in e)}\n")
+        never = [k for k in sorted(ks, key=short) if k not in ran]
+        dead = {k: next((why for sub, why in UNREACHABLE.items() if sub in k), None) for k in never}
+        f.write(f"# not executed: {len(never)} ({sum(1 for v in dead.values() if v)} of them cannot be launched through the library's host code)\n")
+        for k in never:
+            f.write(f"{'UNREACHABLE' if dead[k] else 'NEVER'} {short(k)}" + (f"   -- {dead[k]}" if dead[k] else "") + "\n")
 
 
 if __name__ == "__main__":

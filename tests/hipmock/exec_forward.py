@@ -679,13 +679,23 @@ CASES = {
     "c2bf16": (3, 6, 64, drive.RES64, 1, "forward"),       # bf16 storage / MFMA inputs (case name ends in bf16)
     "c2f32": (3, 6, 64, drive.RES64, 2, "forward"),        # the fp32-compute verification mode (case name ends in f32)
 }
+# kernel-coverage cases of tests/gfx950sim/suite.py (variants no benchmark configuration launches): simulator only, not replayed by
+# tests/test_launch_trace.py
+SIM_CASES = {
+    "big128": (3, 6, 64, ((128, 128), 9, 9), 12, "forward"),           # with BNDM_NO_FUSED: 49152 x 128 outputs = 192 tiles of 256 x 128 (conv_igemm's 3-stage tile)
+    "big128bf16": (3, 6, 64, ((128, 128), 9, 9), 12, "forward"),
+    "w64bf16": (3, 6, 64, ((64, 128, 128), 2, 0), 1, "forward"),       # bf16 instances of the generic kernels (gn_apply, attention, igemm head)
+    "lat256bf16": (4, 8, 32, ((128, 256, 256), 2, 0), 1, "forward"),   # bf16 conv_t32<TH=8> incl. the 32-channel head
+    "vae16bf16": (4, 3, 16, None, 1, "vae"),                           # bf16 softmax_rows (256-token attention of the VAE mid block)
+    "loop16f32": (4, 8, 16, ((128, 128), 9, 9), 1, "iadb"),                # the in-engine loop in fp32 mode (fill_f32_kernel)
+}
 T_IN, DA, DG = [1.0, 0.5], [-0.5, -0.5], [-0.3, -0.2]
 DDIM = [990.0, 0.9, 0.43588989, 0.92, 0.39191836, 980.0, 0.92, 0.39191836, 0.94, 0.34117444]
 
 
 def main():
     libpath, outdir, case = os.path.abspath(sys.argv[1]), sys.argv[2], sys.argv[3]
-    cin, cout, res, layout, B, mode = CASES[case]
+    cin, cout, res, layout, B, mode = {**CASES, **SIM_CASES}[case]
     B = int(os.environ.get("EXEC_BATCH", B))                # (experiments: another batch for the same case)
     MB = int(os.environ.get("EXEC_MAX_BATCH", B))            # handle sized for a larger batch than the call's (tile choices follow it)
     global BF16

@@ -89,7 +89,7 @@ def run_scenario(lib, name, outdir, lanes=1, flags=0):
     return [_mask_unread(_mask_padding(ln), masks) for ln in open(trace).read().splitlines()]
 
 
-def run_script(script, lib, outdir, *args, env=None, mockdir=None):
+def run_script(script, lib, outdir, *args, env=None, mockdir=None, timeout=900):
     """runs tests/hipmock/<script> <lib> <args> under the stand-in -> its stdout (`env`: extra environment of that process)"""
     mock = build_mock(mockdir or outdir)
     os.makedirs(outdir, exist_ok=True)
@@ -99,7 +99,7 @@ def run_script(script, lib, outdir, *args, env=None, mockdir=None):
     env = dict(os.environ, **(env or {}), LD_LIBRARY_PATH=mock + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""), HIPMOCK_TRACE=trace,
                HIPMOCK_KERNARGS=kernargs_file(lib, mockdir or outdir))
     r = subprocess.run([sys.executable, os.path.join(HERE, script), lib, *map(str, args)], env=env, capture_output=True, text=True,
-                       timeout=900)
+                       timeout=timeout)
     assert r.returncode == 0, f"{script} failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
     return r.stdout
 

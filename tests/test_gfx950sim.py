@@ -54,6 +54,40 @@ def test_every_configuration_on_the_simulator(name, workdir):
     _check(suite.run_config(name, work=workdir, procs=int(os.environ.get("GFX950SIM_TEST_PROCS", "8"))))
 
 
+def test_lds_bank_model_lands_on_the_measured_conflict_rates(workdir):
+    """Calibration of the simulator's LDS bank model against hardware counters: profiles/r03_pmc_sq.txt (driver-run, round 3, c2 at B = 64)
+    holds SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS per kernel; conv_s, conv_igemm and temb_mlp are byte-identical to that
+    build (tests/test_launch_trace.py::test_kernels_unchanged_since_the_driver_green_build), and bank conflicts depend on addresses only, so
+    the deep32 run of the fast subset (same kernels, same tile shapes, batch 1) must show the same ratios: conv_s 20.3 % measured"""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("sim_lds_banks", os.path.join(root, "tools", "sim_lds_banks.py"))
+    SB = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(SB)
+    stats = os.path.join(workdir, "deep32_t32x4", "sim_stats_deep32.json")
+    if not os.path.exists(stats):
+        _check(suite.run_config("deep32_t32x4", work=workdir, procs=int(os.environ.get("GFX950SIM_TEST_PROCS", "8"))))
+    meas = SB.measured(os.path.join(root, "profiles", "r03_pmc_sq.txt"))
+    fam = {}
+    for e in json.load(open(stats)):
+        mk = SB.family(e["kernel"])[1]
+        f = fam.setdefault(mk, [0, 0, 0])
+        f[0] += sum(n for m, n in e["insts"].items() if m.startswith("ds_"))
+        f[1] += e["bytes"].get("lds_cycles", 0)
+        f[2] += e["bytes"].get("lds_conflict", 0)
+    rate = lambda k: fam[k][2] / fam[k][1]
+    hw_rate = lambda k: meas[k].get("SQ_LDS_BANK_CONFLICT", 0.0) / meas[k]["SQ_LDS_IDX_ACTIVE"]
+    hw_cpi = lambda k: meas[k]["SQ_LDS_IDX_ACTIVE"] / meas[k]["SQ_INSTS_LDS"]
+    print({k: (round(rate(k), 4), round(fam[k][1] / fam[k][0], 3)) for k in fam if k and fam[k][1]})
+    assert abs(rate("conv_s") - hw_rate("conv_s")) < 0.02, (rate("conv_s"), hw_rate("conv_s"))               # 0.205 vs 0.203
+    assert abs(fam["conv_s"][1] / fam["conv_s"][0] - hw_cpi("conv_s")) < 0.25                                   # LDS cycles per DS instruction
+    assert rate("conv_igemm") == 0.0 and hw_rate("conv_igemm") == 0.0
+    assert abs(fam["conv_igemm"][1] / fam["conv_igemm"][0] - hw_cpi("conv_igemm")) < 0.02                       # 4.00 vs 4.00
+    assert abs(fam["temb_mlp"][1] / fam["temb_mlp"][0] - hw_cpi("temb_mlp")) < 0.05                             # 3.95 vs 3.95
+    assert rate("conv_t32<TH=16>") < 0.06 and rate("conv_t32<TH=8>") < 0.04                                     # (changed since r03: 0.039 / 0.019 there)
+
+
 def test_the_simulator_catches_a_dropped_wait(workdir):
     """Sensitivity: the same library with ONE counted wait of conv_t32 loosened in the instruction stream
     (`s_waitcnt vmcnt(N)` -> `vmcnt(N + 3)` at the K loop's tile wait) must produce hazards or a wrong result -- the

@@ -65,7 +65,8 @@ def oracle_weights(workdir, key, make):
 def _case_network(case):
     """-> (cfg, key, make) of a replay case's network"""
     from oracle import unet_oracle as UO
-    cin, cout, res, layout, B, mode = _CASES[case]
+    from tests.hipmock.exec_forward import SIM_CASES
+    cin, cout, res, layout, B, mode = {**_CASES, **SIM_CASES}[case]
     if mode == "vae":
         from oracle import vae_oracle as VO
         cfg = VO.make_config()
