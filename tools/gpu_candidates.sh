@@ -7,6 +7,12 @@ for c in c2 c4; do for l in bndm_amd/libbndm_hip.so tools/lib_v9.so tools/lib_v1
   echo -n "$c $l  "; timeout 300 python tools/fwd_hash.py $l $c 2>&1 | tail -1; done; done
 echo "== A/B, two interleaved rounds: shipped | v9 staged 1x1 chunks | v12 scalar chunk descriptors | v19 conv_s bank-conflict-free LDS"
 timeout 1500 python tools/ab_libs.py --rounds 2 --acc bndm_amd/libbndm_hip.so tools/lib_v9.so tools/lib_v12.so tools/lib_v19.so 2>&1 | tail -16
+echo "== v19's prediction (profiles/r06_sim_lds_banks.txt): SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of conv_s 20 % on the shipped library, ~1 % (q|k|v launches only) on v19"
+for l in bndm_amd/libbndm_hip.so tools/lib_v19.so; do
+  d=/tmp/pmc_lds_$(basename $l .so); rm -rf $d
+  (cd /tmp && TMPDIR=/tmp timeout 600 rocprofv3 --output-format csv --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS -d $d -- python $R/tools/fwd_hash.py $R/$l c2 > /dev/null 2>&1)
+  echo "-- $l"; python tools/pmc_sum.py $d --match conv_s 2>&1 | tail -6
+done
 echo "== v8 (round-4 patch: pair-granular sums, sums-first prologue; conv_t32<TH=32> only with BNDM_TH32_MIN): accuracy + A/B"
 timeout 1200 python tools/ab_libs.py --rounds 2 --acc bndm_amd/libbndm_hip.so tools/lib_v8.so "tools/lib_v8.so@BNDM_TH32_MIN=256" 2>&1 | tail -12
 echo "== c5 (latent UNet, B = 8 per GPU) under the EXISTING switches: is a batch-size heuristic between tested code paths worth anything?"
